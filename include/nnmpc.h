@@ -1,0 +1,125 @@
+/* nnmpc.h -- C ABI of libnnmpc_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the offline-MPC hot path of
+ * pratyushkumar211/industrial_nnmpc_2021.  Every entry point replaces one
+ * reference interface (file:line into the reference repo):
+ *
+ *   nnmpc_qp_create        <- DenseQPRegulator.__init__/_setup_fixed_matrices
+ *                             (lib/linearMPC.py:339-395): takes the condensed
+ *                             P (n x n) and tq (n x n_aug) the reference builds.
+ *   nnmpc_qp_solve_batch   <- DenseQPRegulator.solve -> cvxopt.solvers.qp(P, tq@x0, G, h)
+ *                             (lib/linearMPC.py:495-512, :503-504) with the
+ *                             box G = blockdiag([I;-I]), h = tile([uub;-ulb])
+ *                             (:476-493), for B independent (x0, ulb, uub).
+ *   nnmpc_nn_create        <- RegulatorLayerWith/WithoutUprev.__init__
+ *                             (lib/LinearMPCLayers.py:22-32, :73-83) /
+ *                             NeuralNetworkController regulator_weights, xscale
+ *                             (lib/controller_evaluation.py:780-839).
+ *   nnmpc_nn_forward       <- RegulatorLayerWith/WithoutUprev.call
+ *                             (lib/LinearMPCLayers.py:40-61, :91-112) ==
+ *                             NeuralNetworkController._get_control_input
+ *                             (lib/controller_evaluation.py:863-892).
+ *
+ * Conventions: plain pointers and sizes only; all matrices row-major; the
+ * caller owns every buffer it passes; a handle owns its device copies and
+ * workspace; functions return 0 on success or a negative NNMPC_E* code and
+ * never throw; nnmpc_last_error() describes the last failure of the calling
+ * thread.  A handle is bound to the HIP device current at create time and is
+ * not re-entrant.  `ptr_kind` says where the per-call buffers live:
+ * NNMPC_HOST (the library stages them through PCIe) or NNMPC_DEVICE (HBM
+ * resident, used in place).
+ */
+#ifndef NNMPC_H
+#define NNMPC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNMPC_OK 0
+#define NNMPC_EINVAL (-1)   /* bad argument */
+#define NNMPC_EHIP (-2)     /* HIP runtime error */
+#define NNMPC_ENOMEM (-3)
+#define NNMPC_ENOTIMPL (-4)
+
+#define NNMPC_HOST 0
+#define NNMPC_DEVICE 1
+
+/* per-problem status written by nnmpc_qp_solve_batch */
+#define NNMPC_ST_OPTIMAL 0   /* KKT conditions verified in fp64 */
+#define NNMPC_ST_MAXITER 1   /* round / polish budget exhausted, not certified */
+#define NNMPC_ST_NUMERIC 2   /* non-positive pivot or NaN */
+
+typedef struct nnmpc_qp nnmpc_qp;
+typedef struct nnmpc_nn nnmpc_nn;
+
+typedef struct {
+  int32_t max_batch;         /* resident problems per wave (rounded up to 128); 0 = 1024 */
+  int32_t nb;                /* Cholesky block 64 | 128; 0 = auto */
+  int32_t max_ipm_iters;     /* 0 = 40 */
+  int32_t max_polish_rounds; /* 0 = 12 */
+  int32_t max_refine;        /* refinement solves per active set; 0 = 10 */
+  int32_t max_rounds;        /* lock-step rounds per wave; 0 = 120 */
+  float ipm_tol;             /* PDIP exit: |r_d|_inf <= tol*max(1,|q|_inf) and mu <= tol; 0 = 1e-3 */
+  double refine_tol;         /* |dx|_inf <= tol*max(1,|x|_inf); 0 = 1e-11 */
+  double bound_tol;          /* primal feasibility slack of the KKT check; 0 = 1e-9 */
+} nnmpc_qp_opts;
+
+typedef struct {
+  int64_t problems;          /* problems solved since the last reset */
+  int64_t rounds;            /* lock-step rounds executed */
+  int64_t factorizations;    /* per-problem Cholesky factorisations */
+  int64_t ipm_iterations;    /* per-problem PDIP iterations */
+  int64_t panel_launches;    /* launches of the dominant kernel (chol_panel) */
+  double panel_ms;           /* hipEvent time of those launches (profiling on) */
+  double diag_ms;            /* same for chol_diag */
+  double trsv_ms;            /* same for trsv */
+  double total_ms;           /* hipEvent time of whole solve_batch calls */
+  double panel_flops;        /* algorithmic flops executed by chol_panel launches */
+} nnmpc_qp_stats;
+
+const char* nnmpc_last_error(void);
+
+/* P: n x n (only the lower triangle is read, like cvxopt does), tq: n x n_aug,
+ * Kunc: n x n_aug warm-start gain (u_unc = Kunc x0 = -P^-1 tq x0) or NULL.
+ * n = N * nu (horizon * inputs per stage); bounds are per stage and tiled. */
+int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const double* P,
+                    const double* tq, const double* Kunc, const nnmpc_qp_opts* opts);
+int nnmpc_qp_destroy(nnmpc_qp* h);
+
+/* x0: B x n_aug, lb/ub: B x nu  ->  u: B x n, active: B x ceil(2n/32) words
+ * (bit i = row i of the reference's G: stage k, rows [k*2nu, k*2nu+nu) upper,
+ * [k*2nu+nu, (k+1)*2nu) lower), status: B, iters: B x 2 (PDIP iterations,
+ * factorisations).  active/status/iters may be NULL. */
+int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double* lb,
+                         const double* ub, double* u, uint32_t* active, int32_t* status,
+                         int32_t* iters, int32_t ptr_kind);
+
+int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on);
+int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset);
+
+/* Kernel-level test hook: factor K_b = mask_b mask_b' o P + diag(dvec_b) and
+ * solve K_b sol_b = rhs_b for b < B <= max_batch (all B x n, host pointers). */
+int nnmpc_qp_debug_factor_solve(nnmpc_qp* h, int32_t B, const float* dvec, const float* mask,
+                                const float* rhs, float* sol);
+
+/* Structured NN controller.  dims = [d_in, h1, ..., h_{L-1}, nu]; W[l] is
+ * dims[l] x dims[l+1] row-major (Keras kernel layout), b[l] has dims[l+1]
+ * entries for l < L-1 (the output layer has no bias).  with_uprev selects
+ * RegulatorLayerWithUprev (d_in = 2 nx + 2 nu) or WithoutUprev (2 nx + nu).
+ * xscale (nx) divides x and xs; NULL = ones.  ulb/uub (nu) clip the output;
+ * NULL = no clipping (the Keras layer). */
+int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims,
+                    const double* const* W, const double* const* b, int32_t nx, int32_t nu,
+                    int32_t with_uprev, const double* xscale, const double* ulb,
+                    const double* uub, int32_t use_bf16, int32_t max_batch);
+int nnmpc_nn_destroy(nnmpc_nn* h);
+/* x, xs: B x nx; uprev (ignored when !with_uprev), us: B x nu; u: B x nu */
+int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* uprev,
+                     const double* xs, const double* us, double* u, int32_t ptr_kind);
+int nnmpc_nn_last_ms(nnmpc_nn* h, double* gemm_ms, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

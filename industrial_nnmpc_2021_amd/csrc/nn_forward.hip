@@ -1,0 +1,258 @@
+// Structured NN controller forward for gfx950:
+//   u = clip( us + MLP([x/xs_scale, (uprev), xs/xs_scale, us])
+//                - MLP([xs/xs_scale, (us),   xs/xs_scale, us]) )
+// Reference: RegulatorLayerWithUprev.call / RegulatorLayerWithoutUprev.call
+// (lib/LinearMPCLayers.py:40-61, :91-112) and its numpy twin
+// NeuralNetworkController._get_control_input (lib/controller_evaluation.py:863-892).
+//
+// Both passes are stacked into one 2B-row activation matrix so every layer is a
+// single MFMA GEMM (C = act(A W + b), weights stored transposed [out][in] so the
+// kernel is the same NT tile GEMM the QP path uses); bias + ReLU are fused in
+// the GEMM epilogue, concat/scale in the assemble kernel and us + (o1 - o2) +
+// clip in the combine kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include "../../include/nnmpc.h"
+#include "gemm_kernels.h"
+#include "common.h"
+
+using namespace nnmpc;
+
+namespace {
+
+// rows [0, Bp): pass 1 inputs, rows [Bp, 2Bp): pass 2 inputs; columns padded to ldk.
+__global__ void nn_assemble_k(float* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
+                              int with_uprev, const double* __restrict__ x,
+                              const double* __restrict__ uprev, const double* __restrict__ xs,
+                              const double* __restrict__ us, const float* __restrict__ inv_scale) {
+  const int din = 2 * nx + (with_uprev ? 2 : 1) * nu;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)2 * Bp * ldk;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int row = (int)(i / ldk), k = (int)(i % ldk);
+    const int pass = row >= Bp, b = pass ? row - Bp : row;
+    float v = 0.f;
+    if (b < B && k < din) {
+      int kk = k;
+      if (kk < nx) {
+        v = (float)(pass ? xs[(size_t)b * nx + kk] : x[(size_t)b * nx + kk]) * inv_scale[kk];
+      } else {
+        kk -= nx;
+        if (with_uprev && kk < nu) {
+          v = (float)(pass ? us[(size_t)b * nu + kk] : uprev[(size_t)b * nu + kk]);
+        } else {
+          if (with_uprev) kk -= nu;
+          if (kk < nx) v = (float)xs[(size_t)b * nx + kk] * inv_scale[kk];
+          else v = (float)us[(size_t)b * nu + (kk - nx)];
+        }
+      }
+    }
+    in[i] = v;
+  }
+}
+
+__global__ void nn_combine_k(double* __restrict__ u, const float* __restrict__ o, int ldo, int Bp,
+                             int B, int nu, const double* __restrict__ us,
+                             const double* __restrict__ ulb, const double* __restrict__ uub,
+                             int clip) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * nu;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int b = (int)(i / nu), c = (int)(i % nu);
+    double v = us[i] + ((double)o[(size_t)b * ldo + c] - (double)o[(size_t)(Bp + b) * ldo + c]);
+    if (clip) { v = v > uub[c] ? uub[c] : v; v = v < ulb[c] ? ulb[c] : v; }
+    u[i] = v;
+  }
+}
+
+}  // namespace
+
+struct nnmpc_nn {
+  int device;
+  int nlayers;             // number of weight matrices
+  std::vector<int> dims;   // nlayers + 1
+  std::vector<int> kpad;   // padded input width of layer l (multiple of 32)
+  std::vector<int> npad;   // padded output width of layer l (multiple of 64)
+  std::vector<float*> Wt;  // [npad][kpad] transposed weights
+  std::vector<float*> bias;  // [npad]
+  int nx, nu, with_uprev, clip, max_batch;
+  float* inv_scale;
+  double *ulb, *uub;
+  float* act[2];           // ping-pong activations [2*max_batch][maxw]
+  int maxw;
+  double *sx, *suprev, *sxs, *sus, *su;  // staging for host pointers
+  hipStream_t stream;
+  hipEvent_t e0, e1, e2, e3;
+  double gemm_ms, total_ms;
+  std::vector<void*> allocs;
+};
+
+namespace {
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e_)); return NNMPC_EHIP; } } while (0)
+
+template <class T>
+int nn_alloc(nnmpc_nn* h, T** p, size_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) { set_error("hipMalloc(%zu) failed", count * sizeof(T)); return NNMPC_ENOMEM; }
+  hipMemset(q, 0, count * sizeof(T));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+template <int NB, bool RELU, bool BIAS>
+void launch_layer(hipStream_t s, float* C, size_t ldc, const float* A, size_t lda, const float* Wt,
+                  size_t ldb, int M, int N, int K, const float* bias) {
+  dim3 grid(N / NB, M / NB);
+  hipLaunchKernelGGL((gemm_nt_f32_k<NB, RELU, BIAS>), grid, dim3(256), TileCfg<NB>::LDS_FLOATS * 4, s,
+                     C, ldc, A, lda, Wt, ldb, K, bias);
+}
+}  // namespace
+
+extern "C" {
+
+int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const double* const* W,
+                    const double* const* b, int32_t nx, int32_t nu, int32_t with_uprev,
+                    const double* xscale, const double* ulb, const double* uub, int32_t use_bf16,
+                    int32_t max_batch) {
+  if (!out || nlayers < 1 || !dims || !W || !b || nx <= 0 || nu <= 0) { set_error("nnmpc_nn_create: bad arguments"); return NNMPC_EINVAL; }
+  if (use_bf16) { set_error("nnmpc_nn_create: bf16 path not built yet"); return NNMPC_ENOTIMPL; }
+  const int din = 2 * nx + (with_uprev ? 2 : 1) * nu;
+  if (dims[0] != din || dims[nlayers] != nu) { set_error("nnmpc_nn_create: dims[0]=%d (want %d), dims[L]=%d (want %d)", dims[0], din, dims[nlayers], nu); return NNMPC_EINVAL; }
+  if ((ulb == nullptr) != (uub == nullptr)) { set_error("nnmpc_nn_create: ulb and uub must both be given or both NULL"); return NNMPC_EINVAL; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("nnmpc_nn_create: no HIP device available (no CPU fallback)"); return NNMPC_EHIP; }
+  nnmpc_nn* h = new nnmpc_nn();
+  hipGetDevice(&h->device);
+  h->nlayers = nlayers; h->nx = nx; h->nu = nu; h->with_uprev = with_uprev; h->clip = ulb != nullptr;
+  h->max_batch = ((std::max(max_batch, 1) + 127) / 128) * 128;
+  h->gemm_ms = h->total_ms = 0;
+  h->dims.assign(dims, dims + nlayers + 1);
+  hipStreamCreate(&h->stream);
+  hipEventCreate(&h->e0); hipEventCreate(&h->e1); hipEventCreate(&h->e2); hipEventCreate(&h->e3);
+  hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
+  hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
+  h->maxw = 0;
+  int rc = 0;
+  for (int l = 0; l < nlayers && !rc; ++l) {
+    const int kp = l == 0 ? ((dims[0] + 31) / 32) * 32 : h->npad[l - 1];
+    const int np_ = ((dims[l + 1] + 63) / 64) * 64;
+    h->kpad.push_back(kp); h->npad.push_back(np_);
+    h->maxw = std::max(h->maxw, std::max(kp, np_));
+    std::vector<float> wt((size_t)np_ * kp, 0.f), bb(np_, 0.f);
+    for (int i = 0; i < dims[l]; ++i)
+      for (int o = 0; o < dims[l + 1]; ++o) wt[(size_t)o * kp + i] = (float)W[l][(size_t)i * dims[l + 1] + o];
+    if (l < nlayers - 1) {
+      if (!b[l]) { set_error("nnmpc_nn_create: missing bias for hidden layer %d", l); rc = NNMPC_EINVAL; break; }
+      for (int o = 0; o < dims[l + 1]; ++o) bb[o] = (float)b[l][o];
+    }
+    float *dw = nullptr, *db = nullptr;
+    rc = nn_alloc(h, &dw, wt.size()); if (rc) break;
+    rc = nn_alloc(h, &db, bb.size()); if (rc) break;
+    hipMemcpy(dw, wt.data(), wt.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(db, bb.data(), bb.size() * 4, hipMemcpyHostToDevice);
+    h->Wt.push_back(dw); h->bias.push_back(db);
+  }
+  std::vector<float> is(nx, 1.f);
+  if (xscale) for (int i = 0; i < nx; ++i) is[i] = (float)(1.0 / xscale[i]);
+  if (!rc) rc = nn_alloc(h, &h->inv_scale, nx);
+  if (!rc) hipMemcpy(h->inv_scale, is.data(), nx * 4, hipMemcpyHostToDevice);
+  if (!rc) rc = nn_alloc(h, &h->ulb, nu);
+  if (!rc) rc = nn_alloc(h, &h->uub, nu);
+  if (!rc && ulb) { hipMemcpy(h->ulb, ulb, nu * 8, hipMemcpyHostToDevice); hipMemcpy(h->uub, uub, nu * 8, hipMemcpyHostToDevice); }
+  const size_t MB = h->max_batch;
+  if (!rc) rc = nn_alloc(h, &h->act[0], 2 * MB * h->maxw);
+  if (!rc) rc = nn_alloc(h, &h->act[1], 2 * MB * h->maxw);
+  if (!rc) rc = nn_alloc(h, &h->sx, MB * nx);
+  if (!rc) rc = nn_alloc(h, &h->sxs, MB * nx);
+  if (!rc) rc = nn_alloc(h, &h->suprev, MB * nu);
+  if (!rc) rc = nn_alloc(h, &h->sus, MB * nu);
+  if (!rc) rc = nn_alloc(h, &h->su, MB * nu);
+  if (rc) { nnmpc_nn_destroy(h); return rc; }
+  *out = h;
+  return NNMPC_OK;
+}
+
+int nnmpc_nn_destroy(nnmpc_nn* h) {
+  if (!h) return NNMPC_OK;
+  hipDeviceSynchronize();
+  for (void* p : h->allocs) hipFree(p);
+  hipEventDestroy(h->e0); hipEventDestroy(h->e1); hipEventDestroy(h->e2); hipEventDestroy(h->e3);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return NNMPC_OK;
+}
+
+int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* uprev, const double* xs,
+                     const double* us, double* u, int32_t ptr_kind) {
+  if (!h || B < 0 || !x || !xs || !us || !u || (h->with_uprev && !uprev)) { set_error("nnmpc_nn_forward: bad arguments"); return NNMPC_EINVAL; }
+  if (B == 0) return NNMPC_OK;
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const int nx = h->nx, nu = h->nu, MB = h->max_batch;
+  double gemm_ms = 0.0;
+  hipEventRecord(h->e0, s);
+  for (int b0 = 0; b0 < B; b0 += MB) {
+    const int nb = std::min(MB, B - b0);
+    const int Bp = ((nb + 127) / 128) * 128;
+    const double *dx, *dup, *dxs, *dus; double* du;
+    if (ptr_kind == NNMPC_HOST) {
+      HIPCHK(hipMemcpyAsync(h->sx, x + (size_t)b0 * nx, (size_t)nb * nx * 8, hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(h->sxs, xs + (size_t)b0 * nx, (size_t)nb * nx * 8, hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(h->sus, us + (size_t)b0 * nu, (size_t)nb * nu * 8, hipMemcpyHostToDevice, s));
+      if (h->with_uprev) HIPCHK(hipMemcpyAsync(h->suprev, uprev + (size_t)b0 * nu, (size_t)nb * nu * 8, hipMemcpyHostToDevice, s));
+      dx = h->sx; dxs = h->sxs; dus = h->sus; dup = h->suprev; du = h->su;
+    } else {
+      dx = x + (size_t)b0 * nx; dxs = xs + (size_t)b0 * nx; dus = us + (size_t)b0 * nu;
+      dup = h->with_uprev ? uprev + (size_t)b0 * nu : nullptr; du = u + (size_t)b0 * nu;
+    }
+    hipLaunchKernelGGL(nn_assemble_k, dim3(2048), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
+                       h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
+    hipEventRecord(h->e2, s);
+    int cur = 0;
+    const int M = 2 * Bp;
+    for (int l = 0; l < h->nlayers; ++l) {
+      const int K = h->kpad[l], N = h->npad[l];
+      float* C = h->act[cur ^ 1];
+      const float* A = h->act[cur];
+      const bool last = l == h->nlayers - 1;
+      if (N % 128 == 0) {
+        if (last) launch_layer<128, false, false>(s, C, N, A, K, h->Wt[l], K, M, N, K, nullptr);
+        else launch_layer<128, true, true>(s, C, N, A, K, h->Wt[l], K, M, N, K, h->bias[l]);
+      } else {
+        if (last) launch_layer<64, false, false>(s, C, N, A, K, h->Wt[l], K, M, N, K, nullptr);
+        else launch_layer<64, true, true>(s, C, N, A, K, h->Wt[l], K, M, N, K, h->bias[l]);
+      }
+      cur ^= 1;
+    }
+    hipEventRecord(h->e3, s);
+    hipLaunchKernelGGL(nn_combine_k, dim3(1024), dim3(256), 0, s, du, h->act[cur], h->npad[h->nlayers - 1], Bp,
+                       nb, nu, dus, h->ulb, h->uub, h->clip);
+    if (ptr_kind == NNMPC_HOST) HIPCHK(hipMemcpyAsync(u + (size_t)b0 * nu, h->su, (size_t)nb * nu * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->e2, h->e3);
+    gemm_ms += ms;
+  }
+  hipEventRecord(h->e1, s);
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  float tot = 0.f;
+  hipEventElapsedTime(&tot, h->e0, h->e1);
+  h->gemm_ms = gemm_ms; h->total_ms = tot;
+  return NNMPC_OK;
+}
+
+int nnmpc_nn_last_ms(nnmpc_nn* h, double* gemm_ms, double* total_ms) {
+  if (!h) return NNMPC_EINVAL;
+  if (gemm_ms) *gemm_ms = h->gemm_ms;
+  if (total_ms) *total_ms = h->total_ms;
+  return NNMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,886 @@
+// Batched box-constrained condensed-QP solver for gfx950 (MI355X).
+//
+//   min 1/2 u'Pu + (tq x0)'u   s.t.  lb <= u_k <= ub  (k = 0..N-1)
+//
+// replaces DenseQPRegulator.solve -> cvxopt.solvers.qp of the reference
+// (lib/linearMPC.py:495-512) for B independent (x0, lb, ub) at once.
+//
+// Algorithm per problem (all problems of a wave advance in lock-step "rounds",
+// a per-problem state machine on the device decides what each round does):
+//   PDIP   Mehrotra predictor-corrector on the reduced KKT system
+//          (P + diag(z_u/s_u + z_l/s_l)) du = r, f32 Cholesky (MFMA) + 2 solves,
+//          warm-started at the clipped unconstrained minimiser, run only until
+//          the active set is identifiable (ipm_tol).
+//   POLISH active set from z > s; solve the free block exactly: f32 Cholesky of
+//          the masked P + iterative refinement with f64 residuals (P, q in f64),
+//          then an f64 KKT check; a failed check updates the set (primal-dual
+//          active-set step) and repeats.  status OPTIMAL = KKT verified in f64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include "../../include/nnmpc.h"
+#include "chol_kernels.h"
+#include "gemm_kernels.h"
+#include "common.h"
+
+using namespace nnmpc;
+
+namespace {
+
+enum { PH_INIT = 0, PH_IPM = 1, PH_POLISH = 2, PH_DONE = 3 };
+enum { CNT_ACTIVE = 0, CNT_FACTOR = 1, CNT_IPM = 2, CNT_POLISH = 3, CNT_SOLVE1 = 4, CNT_PS1 = 5 };
+
+struct QpDev {
+  int n, np, nu, slots;
+  int max_ipm, max_polish, max_refine;
+  float ipm_tol;
+  double refine_tol, bound_tol, stat_tol;
+  // f32 [slots][np]
+  float *u, *zu, *zl, *lbv, *ubv, *q, *PU, *rd, *rhs, *sol, *dua, *dvec, *mask, *uunc;
+  // f64 [slots][np]
+  double *x, *q64, *PX;
+  unsigned char* st;  // [slots][np]  0 free, 1 at upper, 2 at lower
+  const double *lb64, *ub64;  // [slots][nu]
+  int *phase, *f_factor, *f_solve1, *f_solve2, *ipm_it, *nfac, *prounds, *rcnt, *rconv, *newset,
+      *fail;
+  float *mu, *gap, *smu, *qscale;
+  int* counters;
+  double* u_out;       // [slots][n]
+  uint32_t* act_out;   // [slots][words]
+  int* status_out;     // [slots]
+  int* iters_out;      // [slots][2]
+  int words;
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_maxd(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+// All 256 threads must call; result broadcast to all.
+__device__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ double block_maxd(double v, double* sh) {
+  v = wave_maxd(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+__device__ int block_sum_i(int v, int* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+#define SLACK_MIN 1e-12f
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_k(QpDev d, int nprob) {
+  __shared__ float shf[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  if (p >= nprob) {  // unused slot of this wave
+    if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
+    for (int r = tid; r < d.np; r += 256) { d.u[o + r] = 0.f; d.x[o + r] = 0.0; }
+    return;
+  }
+  float qm = 0.f;
+  for (int r = tid; r < d.np; r += 256) {
+    if (r < d.n) {
+      const int c = r % d.nu;
+      const float lb = (float)d.lb64[(size_t)p * d.nu + c], ub = (float)d.ub64[(size_t)p * d.nu + c];
+      const float q = (float)d.q64[o + r];
+      const float w = ub - lb;
+      float u0 = d.uunc[o + r];
+      u0 = fminf(fmaxf(u0, lb + 0.05f * w), ub - 0.05f * w);
+      d.lbv[o + r] = lb; d.ubv[o + r] = ub; d.q[o + r] = q; d.u[o + r] = u0;
+      d.zu[o + r] = 0.f; d.zl[o + r] = 0.f;
+      qm = fmaxf(qm, fabsf(q));
+    } else {
+      d.lbv[o + r] = -1.f; d.ubv[o + r] = 1.f; d.q[o + r] = 0.f; d.u[o + r] = 0.f;
+      d.zu[o + r] = 0.f; d.zl[o + r] = 0.f; d.q64[o + r] = 0.0;
+    }
+    d.mask[o + r] = 1.f; d.dvec[o + r] = 0.f; d.rhs[o + r] = 0.f; d.sol[o + r] = 0.f;
+    d.dua[o + r] = 0.f; d.rd[o + r] = 0.f; d.x[o + r] = 0.0; d.st[o + r] = 0;
+  }
+  qm = block_max(qm, shf);
+  if (tid == 0) {
+    d.qscale[p] = fmaxf(1.f, qm);
+    d.phase[p] = PH_INIT;
+    d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
+    d.ipm_it[p] = d.nfac[p] = d.prounds[p] = d.rcnt[p] = d.rconv[p] = d.newset[p] = d.fail[p] = 0;
+    d.mu[p] = d.gap[p] = d.smu[p] = 0.f;
+  }
+}
+
+__device__ void write_outputs(const QpDev& d, int p, int status) {
+  const int tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  for (int r = tid; r < d.n; r += 256) d.u_out[(size_t)p * d.n + r] = d.x[o + r];
+  const int m = 2 * d.n;
+  for (int w = tid; w < d.words; w += 256) {
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int idx = 32 * w + b;
+      if (idx < m) {
+        const int k = idx / (2 * d.nu), c = idx % (2 * d.nu);
+        const int hit = (c < d.nu) ? (d.st[o + k * d.nu + c] == 1) : (d.st[o + k * d.nu + c - d.nu] == 2);
+        bits |= (uint32_t)hit << b;
+      }
+    }
+    d.act_out[(size_t)p * d.words + w] = bits;
+  }
+  if (tid == 0) {
+    d.status_out[p] = d.fail[p] ? NNMPC_ST_NUMERIC : status;
+    d.iters_out[2 * p] = d.ipm_it[p];
+    d.iters_out[2 * p + 1] = d.nfac[p];
+  }
+}
+
+// Round stage 1: needs PU = P u (f32) for INIT/IPM slots, PX = P x (f64) for POLISH slots.
+__global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
+  __shared__ float shf[4];
+  __shared__ int shi[4];
+  __shared__ double shd[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  int ph = d.phase[p];
+  if (ph == PH_DONE) return;
+  const int n = d.n;
+
+  if (ph == PH_INIT) {
+    float s = 0.f;
+    for (int r = tid; r < n; r += 256) s += fabsf(d.PU[o + r] + d.q[o + r]);
+    s = block_sum(s, shf);
+    const float mu0 = 0.1f * s / n + 1e-3f;
+    for (int r = tid; r < n; r += 256) {
+      const float g = d.PU[o + r] + d.q[o + r];
+      const float u = d.u[o + r];
+      const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+      d.zu[o + r] = fmaxf(-g, 0.f) + mu0 / su;
+      d.zl[o + r] = fmaxf(g, 0.f) + mu0 / sl;
+    }
+    ph = PH_IPM;
+  }
+
+  if (ph == PH_IPM) {
+    float rdm = 0.f, gs = 0.f;
+    for (int r = tid; r < n; r += 256) {
+      const float g = d.PU[o + r] + d.q[o + r];
+      const float u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+      const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+      const float rdv = g + zu - zl;
+      d.rd[o + r] = rdv;
+      rdm = fmaxf(rdm, fabsf(rdv));
+      gs += su * zu + sl * zl;
+    }
+    rdm = block_max(rdm, shf);
+    gs = block_sum(gs, shf);
+    const float mu = gs / (2.f * n);
+    const int it = d.ipm_it[p];
+    const bool nan = !(rdm == rdm) || !(gs == gs);
+    const bool conv = (rdm <= d.ipm_tol * d.qscale[p] && mu <= d.ipm_tol) || it >= d.max_ipm || nan;
+    if (!conv) {
+      for (int r = tid; r < n; r += 256) {
+        const float u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+        const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+        d.dvec[o + r] = zu / su + zl / sl;
+        d.mask[o + r] = 1.f;
+        d.rhs[o + r] = -(d.PU[o + r] + d.q[o + r]);
+      }
+      if (tid == 0) {
+        d.phase[p] = PH_IPM;
+        d.gap[p] = gs; d.mu[p] = mu;
+        d.ipm_it[p] = it + 1; d.nfac[p] += 1;
+        d.f_factor[p] = 1; d.f_solve1[p] = 1; d.f_solve2[p] = 1;
+        atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_FACTOR], 1);
+        atomicAdd(&d.counters[CNT_IPM], 1); atomicAdd(&d.counters[CNT_SOLVE1], 1);
+      }
+      return;
+    }
+    // ---- PDIP done: guess the active set, start the polish next round
+    for (int r = tid; r < n; r += 256) {
+      const float u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+      const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+      const int c = r % d.nu;
+      int s = 0;
+      if (!nan) {
+        const bool au = zu > su, al = zl > sl;
+        if (au && al) s = (zu * sl > zl * su) ? 1 : 2; else if (au) s = 1; else if (al) s = 2;
+      }
+      d.st[o + r] = (unsigned char)s;
+      d.x[o + r] = s == 1 ? d.ub64[(size_t)p * d.nu + c]
+                 : s == 2 ? d.lb64[(size_t)p * d.nu + c]
+                          : (nan ? 0.0 : (double)u);
+    }
+    if (tid == 0) {
+      if (nan) d.fail[p] = 1;
+      d.phase[p] = PH_POLISH; d.newset[p] = 1; d.rcnt[p] = 0; d.rconv[p] = 0; d.prounds[p] = 0;
+      d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
+      atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
+    }
+    return;
+  }
+
+  // ---- PH_POLISH: g = P x + q in f64
+  if (d.rconv[p]) {
+    // KKT check on the refined point
+    int bad = 0;
+    double gfree = 0.0;
+    for (int r = tid; r < n; r += 256) {
+      const int c = r % d.nu;
+      const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
+      const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
+      const int s = d.st[o + r];
+      if (s == 0) { bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); gfree = fmax(gfree, fabs(g)); }
+      else if (s == 1) bad += (g >= 0.0);   // multiplier -g must be > 0
+      else bad += (g <= 0.0);               // multiplier  g must be > 0
+    }
+    bad = block_sum_i(bad, shi);
+    gfree = block_maxd(gfree, shd);
+    if (bad == 0) {
+      // stationarity of the free block certifies the refinement itself
+      write_outputs(d, p, gfree <= d.stat_tol * (double)d.qscale[p] ? NNMPC_ST_OPTIMAL : NNMPC_ST_MAXITER);
+      if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
+      return;
+    }
+    const int pr = d.prounds[p] + 1;
+    if (pr > d.max_polish) {
+      write_outputs(d, p, NNMPC_ST_MAXITER);
+      if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
+      return;
+    }
+    for (int r = tid; r < n; r += 256) {
+      const int c = r % d.nu;
+      const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
+      const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
+      const int s = d.st[o + r];
+      if (s == 0) {
+        if (x > ub + d.bound_tol) { d.st[o + r] = 1; d.x[o + r] = ub; }
+        else if (x < lb - d.bound_tol) { d.st[o + r] = 2; d.x[o + r] = lb; }
+      } else if ((s == 1 && g >= 0.0) || (s == 2 && g <= 0.0)) {
+        d.st[o + r] = 0;
+      }
+    }
+    if (tid == 0) {
+      d.prounds[p] = pr; d.newset[p] = 1; d.rcnt[p] = 0; d.rconv[p] = 0;
+      d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;  // P x is stale: re-solve next round
+      atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
+    }
+    return;
+  }
+  // refinement solve:  K_FF dx_F = -(P x + q)_F
+  const int ns = d.newset[p];
+  for (int r = tid; r < n; r += 256) {
+    const int s = d.st[o + r];
+    d.rhs[o + r] = s ? 0.f : (float)(-(d.PX[o + r] + d.q64[o + r]));
+    if (ns) { d.mask[o + r] = s ? 0.f : 1.f; d.dvec[o + r] = s ? 1.f : 0.f; }
+  }
+  if (tid == 0) {
+    d.f_factor[p] = ns; d.f_solve1[p] = 1; d.f_solve2[p] = 0;
+    if (ns) { d.nfac[p] += 1; d.newset[p] = 0; atomicAdd(&d.counters[CNT_FACTOR], 1); }
+    atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
+    atomicAdd(&d.counters[CNT_SOLVE1], 1); atomicAdd(&d.counters[CNT_PS1], 1);
+  }
+}
+
+// x += dx, decide whether the refinement has converged (shared by mid / post).
+__device__ void polish_update(const QpDev& d, int p, double* shd) {
+  const int tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  double dxm = 0.0, xm = 0.0;
+  for (int r = tid; r < d.n; r += 256) {
+    if (d.st[o + r] == 0) {
+      const double dx = (double)d.sol[o + r];
+      const double x = d.x[o + r] + dx;
+      d.x[o + r] = x;
+      dxm = fmax(dxm, fabs(dx));
+      xm = fmax(xm, fabs(x));
+    }
+  }
+  dxm = block_maxd(dxm, shd);
+  xm = block_maxd(xm, shd);
+  if (tid == 0) {
+    const int rc = d.rcnt[p] + 1;
+    d.rcnt[p] = rc;
+    const bool nan = !(dxm == dxm);
+    if (nan) d.fail[p] = 1;
+    d.rconv[p] = (dxm <= d.refine_tol * fmax(1.0, xm)) || rc >= d.max_refine || nan;
+  }
+}
+
+// Round stage 2 (after solve #1).
+__global__ __launch_bounds__(256) void stage_mid_k(QpDev d) {
+  __shared__ float shf[4];
+  __shared__ double shd[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  if (!d.f_solve1[p]) return;
+  const int ph = d.phase[p], n = d.n;
+  if (ph == PH_POLISH) {
+    polish_update(d, p, shd);
+    __syncthreads();
+    if (tid == 0) d.f_solve2[p] = !d.rconv[p];
+    return;
+  }
+  // IPM: affine (predictor) direction -> sigma -> corrector right-hand side
+  float t = 0.f;
+  for (int r = tid; r < n; r += 256) {
+    const float du = d.sol[o + r], u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+    const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+    const float dzu = -zu + zu * du / su, dzl = -zl - zl * du / sl;
+    t = fmaxf(t, fmaxf(fmaxf(du / su, -du / sl), fmaxf(-dzu / zu, -dzl / zl)));
+  }
+  t = block_max(t, shf);
+  const float a = t > 0.f ? fminf(1.f, 1.f / t) : 1.f;
+  float ga = 0.f;
+  for (int r = tid; r < n; r += 256) {
+    const float du = d.sol[o + r], u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+    const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+    const float dzu = -zu + zu * du / su, dzl = -zl - zl * du / sl;
+    ga += (su - a * du) * (zu + a * dzu) + (sl + a * du) * (zl + a * dzl);
+  }
+  ga = block_sum(ga, shf);
+  float sg = ga / d.gap[p];
+  sg = fminf(1.f, fmaxf(0.f, sg));
+  const float smu = sg * sg * sg * d.mu[p];
+  for (int r = tid; r < n; r += 256) {
+    const float du = d.sol[o + r], u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+    const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+    const float dzu = -zu + zu * du / su, dzl = -zl - zl * du / sl;
+    d.rhs[o + r] = -d.rd[o + r] + zu - smu / su - du * dzu / su - zl + smu / sl - du * dzl / sl;
+    d.dua[o + r] = du;
+  }
+  if (tid == 0) d.smu[p] = smu;
+}
+
+// Round stage 2b: polish slots that take a second refinement solve this round
+// (PX was recomputed from the updated x).
+__global__ __launch_bounds__(256) void stage_mid2_k(QpDev d) {
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  if (d.phase[p] != PH_POLISH || !d.f_solve1[p] || !d.f_solve2[p]) return;
+  for (int r = tid; r < d.n; r += 256)
+    d.rhs[o + r] = d.st[o + r] ? 0.f : (float)(-(d.PX[o + r] + d.q64[o + r]));
+}
+
+// Round stage 3 (after solve #2).
+__global__ __launch_bounds__(256) void stage_post_k(QpDev d) {
+  __shared__ float shf[4];
+  __shared__ double shd[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  if (!d.f_solve2[p]) return;
+  const int ph = d.phase[p], n = d.n;
+  if (ph == PH_POLISH) { polish_update(d, p, shd); return; }
+  const float smu = d.smu[p];
+  float t = 0.f;
+  for (int r = tid; r < n; r += 256) {
+    const float du = d.sol[o + r], da = d.dua[o + r], u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+    const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+    const float dzua = -zu + zu * da / su, dzla = -zl - zl * da / sl;
+    const float rcu = -su * zu + smu + da * dzua, rcl = -sl * zl + smu - da * dzla;
+    const float dzu = (rcu + zu * du) / su, dzl = (rcl - zl * du) / sl;
+    t = fmaxf(t, fmaxf(fmaxf(du / su, -du / sl), fmaxf(-dzu / zu, -dzl / zl)));
+  }
+  t = block_max(t, shf);
+  const float a = t > 0.f ? fminf(1.f, 0.99f / t) : 1.f;
+  for (int r = tid; r < n; r += 256) {
+    const float du = d.sol[o + r], da = d.dua[o + r], u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
+    const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
+    const float dzua = -zu + zu * da / su, dzla = -zl - zl * da / sl;
+    const float rcu = -su * zu + smu + da * dzua, rcl = -sl * zl + smu - da * dzla;
+    const float dzu = (rcu + zu * du) / su, dzl = (rcl - zl * du) / sl;
+    d.u[o + r] = u + a * du;
+    d.zu[o + r] = fmaxf(zu + a * dzu, 1e-30f);
+    d.zl[o + r] = fmaxf(zl + a * dzl, 1e-30f);
+  }
+}
+
+// Budget exhausted: emit whatever we have, uncertified.
+__global__ __launch_bounds__(256) void force_finish_k(QpDev d) {
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  const int ph = d.phase[p];
+  if (ph == PH_DONE) return;
+  if (ph != PH_POLISH) {
+    for (int r = tid; r < d.n; r += 256) { d.x[o + r] = (double)d.u[o + r]; d.st[o + r] = 0; }
+    __syncthreads();
+  }
+  write_outputs(d, p, NNMPC_ST_MAXITER);
+  if (tid == 0) d.phase[p] = PH_DONE;
+}
+
+__global__ void f64_to_f32_k(float* dst, const double* src, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) dst[i] = (float)src[i];
+}
+// x0 [nprob][n_aug] f64 -> padded [rows][ka] f64 and f32
+__global__ void pad_x0_k(double* d64, float* d32, const double* src, int nprob, int n_aug, int ka,
+                         int rows) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)rows * ka;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int p = (int)(i / ka), k = (int)(i % ka);
+    const double v = (p < nprob && k < n_aug) ? src[(size_t)p * n_aug + k] : 0.0;
+    d64[i] = v;
+    d32[i] = (float)v;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+struct nnmpc_qp {
+  int device;
+  int n, np, nu, n_aug, ka, NB, T, tiles, slots, words;
+  nnmpc_qp_opts opts;
+  bool have_kunc;
+  // shared problem data
+  float* Pt;      // tile-packed lower, f32
+  float* P32;     // full np x np, f32
+  double* P64;    // full np x np, f64
+  double* tq64;   // np x ka
+  float* Kunc32;  // np x ka
+  // per-slot workspace
+  float* L;
+  float* Y;
+  QpDev d;
+  double *x0_64;  // [slots][ka]
+  float* x0_32;
+  double *lb_d, *ub_d;  // [slots][nu]
+  double* in_stage;     // device staging for host inputs
+  hipStream_t stream;
+  bool profiling;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used;
+  struct EvRec { int kind; size_t e0, e1; double flops; };
+  std::vector<EvRec> ev_recs;
+  nnmpc_qp_stats stats;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(nnmpc_qp* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) { set_error("hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e)); return NNMPC_ENOMEM; }
+  e = hipMemset(q, 0, count * sizeof(T));
+  if (e != hipSuccess) { set_error("hipMemset: %s", hipGetErrorString(e)); return NNMPC_EHIP; }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+size_t ev_get(nnmpc_qp* h) {
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    h->ev_pool.push_back(e);
+  }
+  return h->ev_used++;
+}
+struct EvScope {
+  nnmpc_qp* h; int kind; double flops; size_t e0;
+  EvScope(nnmpc_qp* h_, int kind_, double flops_) : h(h_), kind(kind_), flops(flops_), e0(0) {
+    if (h->profiling) { e0 = ev_get(h); hipEventRecord(h->ev_pool[e0], h->stream); }
+  }
+  ~EvScope() {
+    if (h->profiling) {
+      size_t e1 = ev_get(h);
+      hipEventRecord(h->ev_pool[e1], h->stream);
+      h->ev_recs.push_back({kind, e0, e1, flops});
+    }
+  }
+};
+void ev_collect(nnmpc_qp* h) {
+  for (auto& r : h->ev_recs) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->ev_pool[r.e0], h->ev_pool[r.e1]);
+    if (r.kind == 0) { h->stats.panel_ms += ms; h->stats.panel_launches += 1; h->stats.panel_flops += r.flops; }
+    else if (r.kind == 1) h->stats.diag_ms += ms;
+    else if (r.kind == 2) h->stats.trsv_ms += ms;
+    else if (r.kind == 3) h->stats.total_ms += ms;
+  }
+  h->ev_recs.clear();
+  h->ev_used = 0;
+}
+
+template <int NB>
+void launch_gemm32(hipStream_t s, float* C, size_t ldc, const float* A, size_t lda, const float* B,
+                   size_t ldb, int M, int N, int K) {
+  dim3 grid(N / NB, M / NB);
+  hipLaunchKernelGGL((gemm_nt_f32_k<NB, false, false>), grid, dim3(256), TileCfg<NB>::LDS_FLOATS * 4, s,
+                     C, ldc, A, lda, B, ldb, K, (const float*)nullptr);
+}
+void gemm32(nnmpc_qp* h, float* C, size_t ldc, const float* A, size_t lda, const float* B, size_t ldb,
+            int M, int N, int K) {
+  if (N % 128 == 0 && M % 128 == 0) launch_gemm32<128>(h->stream, C, ldc, A, lda, B, ldb, M, N, K);
+  else launch_gemm32<64>(h->stream, C, ldc, A, lda, B, ldb, M, N, K);
+}
+void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, const double* B,
+            size_t ldb, int M, int N, int K) {
+  dim3 grid(N / 64, M / 64);
+  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K);
+}
+
+template <int NB>
+int set_lds_attrs() {
+  hipError_t e;
+  e = hipFuncSetAttribute((const void*)chol_diag_k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, chol_diag_lds_bytes<NB>());
+  if (e != hipSuccess) return -1;
+  e = hipFuncSetAttribute((const void*)chol_panel_k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, chol_panel_lds_bytes<NB>());
+  if (e != hipSuccess) return -1;
+  e = hipFuncSetAttribute((const void*)trsv_k<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  if (e != hipSuccess) return -1;
+  e = hipFuncSetAttribute((const void*)gemm_nt_f32_k<NB, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<NB>::LDS_FLOATS * 4);
+  if (e != hipSuccess) return -1;
+  return 0;
+}
+
+template <int NB>
+void factor_all(nnmpc_qp* h, int nslots, int nfactor) {
+  CholArgs a;
+  a.n = h->n; a.np = h->np; a.T = h->T; a.tiles = h->tiles;
+  a.Pt = h->Pt; a.L = h->L; a.Y = h->Y; a.dvec = h->d.dvec; a.mask = h->d.mask;
+  a.flag = h->d.f_factor; a.fail = h->d.fail;
+  const double nb = NB;
+  for (int j = 0; j < h->T; ++j) {
+    {
+      EvScope es(h, 1, 0.0);
+      hipLaunchKernelGGL((chol_diag_k<NB>), dim3(nslots), dim3(256), chol_diag_lds_bytes<NB>(), h->stream, a, j);
+    }
+    const int below = h->T - 1 - j;
+    if (below > 0) {
+      // algorithmic flops of this launch: per tile 2 NB^2 (j NB) update + NB^3 triangular solve
+      const double fl = (double)nfactor * below * (2.0 * nb * nb * (j * nb) + nb * nb * nb);
+      EvScope es(h, 0, fl);
+      hipLaunchKernelGGL((chol_panel_k<NB>), dim3(below, nslots), dim3(256), chol_panel_lds_bytes<NB>(), h->stream, a, j);
+    }
+  }
+}
+template <int NB>
+void solve_all(nnmpc_qp* h, int nslots, const int* flag) {
+  TrsvArgs a;
+  a.n = h->n; a.np = h->np; a.T = h->T; a.tiles = h->tiles;
+  a.L = h->L; a.Y = h->Y; a.rhs = h->d.rhs; a.sol = h->d.sol; a.flag = flag;
+  EvScope es(h, 2, 0.0);
+  hipLaunchKernelGGL((trsv_k<NB>), dim3(nslots), dim3(256), (h->np + 5 * NB) * 4, h->stream, a);
+}
+void factor_dispatch(nnmpc_qp* h, int nslots, int nfactor) {
+  if (h->NB == 128) factor_all<128>(h, nslots, nfactor); else factor_all<64>(h, nslots, nfactor);
+}
+void solve_dispatch(nnmpc_qp* h, int nslots, const int* flag) {
+  if (h->NB == 128) solve_all<128>(h, nslots, flag); else solve_all<64>(h, nslots, flag);
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e_)); return NNMPC_EHIP; } } while (0)
+
+int solve_wave(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_dev, const double* ub_dev,
+               double* u_dev, uint32_t* act_dev, int32_t* st_dev, int32_t* it_dev) {
+  QpDev& d = h->d;
+  hipStream_t s = h->stream;
+  const int slots = h->slots;
+  const int rows = ((nprob + 127) / 128) * 128;  // rows touched by GEMMs / per-slot kernels
+  d.lb64 = lb_dev; d.ub64 = ub_dev;
+  // q = tq x0 (f64), warm start u_unc = Kunc x0 (f32)
+  hipLaunchKernelGGL(pad_x0_k, dim3(256), dim3(256), 0, s, h->x0_64, h->x0_32, x0_dev, nprob, h->n_aug, h->ka, rows);
+  gemm64(h, d.q64, h->np, h->x0_64, h->ka, h->tq64, h->ka, rows, h->np, h->ka);
+  if (h->have_kunc) gemm32(h, d.uunc, h->np, h->x0_32, h->ka, h->Kunc32, h->ka, rows, h->np, h->ka);
+  else HIPCHK(hipMemsetAsync(d.uunc, 0, (size_t)rows * h->np * sizeof(float), s));
+  hipLaunchKernelGGL(init_k, dim3(rows), dim3(256), 0, s, d, nprob);
+
+  int cnt[8];
+  bool any_ipm = true, any_polish = false;
+  int round = 0;
+  for (; round < h->opts.max_rounds; ++round) {
+    HIPCHK(hipMemsetAsync(d.counters, 0, 8 * sizeof(int), s));
+    if (any_ipm) gemm32(h, d.PU, h->np, d.u, h->np, h->P32, h->np, rows, h->np, h->np);
+    if (any_polish) gemm64(h, d.PX, h->np, d.x, h->np, h->P64, h->np, rows, h->np, h->np);
+    hipLaunchKernelGGL(stage_pre_k, dim3(rows), dim3(256), 0, s, d);
+    HIPCHK(hipMemcpyAsync(cnt, d.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (cnt[CNT_ACTIVE] == 0) break;
+    any_ipm = cnt[CNT_IPM] > 0;
+    any_polish = cnt[CNT_POLISH] > 0;
+    h->stats.rounds += 1;
+    h->stats.factorizations += cnt[CNT_FACTOR];
+    h->stats.ipm_iterations += cnt[CNT_IPM];
+    if (cnt[CNT_FACTOR] > 0) factor_dispatch(h, rows, cnt[CNT_FACTOR]);
+    if (cnt[CNT_SOLVE1] > 0) {
+      solve_dispatch(h, rows, d.f_solve1);
+      hipLaunchKernelGGL(stage_mid_k, dim3(rows), dim3(256), 0, s, d);
+      if (cnt[CNT_PS1] > 0) {
+        gemm64(h, d.PX, h->np, d.x, h->np, h->P64, h->np, rows, h->np, h->np);
+        hipLaunchKernelGGL(stage_mid2_k, dim3(rows), dim3(256), 0, s, d);
+      }
+      solve_dispatch(h, rows, d.f_solve2);
+      hipLaunchKernelGGL(stage_post_k, dim3(rows), dim3(256), 0, s, d);
+    }
+  }
+  if (round == h->opts.max_rounds) hipLaunchKernelGGL(force_finish_k, dim3(rows), dim3(256), 0, s, d);
+  // outputs
+  HIPCHK(hipMemcpyAsync(u_dev, d.u_out, (size_t)nprob * h->n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (act_dev) HIPCHK(hipMemcpyAsync(act_dev, d.act_out, (size_t)nprob * h->words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  if (st_dev) HIPCHK(hipMemcpyAsync(st_dev, d.status_out, (size_t)nprob * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (it_dev) HIPCHK(hipMemcpyAsync(it_dev, d.iters_out, (size_t)nprob * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  h->stats.problems += nprob;
+  (void)slots;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const double* P,
+                    const double* tq, const double* Kunc, const nnmpc_qp_opts* opts) {
+  if (!out || !P || !tq || n <= 0 || nu <= 0 || n_aug <= 0 || n % nu != 0) {
+    set_error("nnmpc_qp_create: bad arguments (n=%d nu=%d n_aug=%d)", n, nu, n_aug);
+    return NNMPC_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("nnmpc_qp_create: no HIP device available (this library has no CPU fallback)");
+    return NNMPC_EHIP;
+  }
+  nnmpc_qp* h = new nnmpc_qp();
+  memset(&h->stats, 0, sizeof(h->stats));
+  memset(&h->d, 0, sizeof(h->d));
+  h->profiling = false; h->ev_used = 0;
+  if (opts) h->opts = *opts; else memset(&h->opts, 0, sizeof(h->opts));
+  nnmpc_qp_opts& o = h->opts;
+  if (o.max_batch <= 0) o.max_batch = 1024;
+  if (o.nb == 0) o.nb = (n <= 1024) ? 64 : 128;
+  if (o.nb != 64 && o.nb != 128) { set_error("nb must be 64 or 128"); delete h; return NNMPC_EINVAL; }
+  if (o.max_ipm_iters <= 0) o.max_ipm_iters = 40;
+  if (o.max_polish_rounds <= 0) o.max_polish_rounds = 12;
+  if (o.max_refine <= 0) o.max_refine = 10;
+  if (o.max_rounds <= 0) o.max_rounds = 120;
+  if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-3f;
+  if (o.refine_tol <= 0.0) o.refine_tol = 1e-11;
+  if (o.bound_tol <= 0.0) o.bound_tol = 1e-9;
+  hipGetDevice(&h->device);
+  h->n = n; h->nu = nu; h->n_aug = n_aug;
+  h->NB = o.nb;
+  h->np = ((n + h->NB - 1) / h->NB) * h->NB;
+  h->T = h->np / h->NB;
+  h->tiles = h->T * (h->T + 1) / 2;
+  h->ka = ((n_aug + 31) / 32) * 32;
+  h->slots = ((o.max_batch + 127) / 128) * 128;
+  h->words = (2 * n + 31) / 32;
+  h->have_kunc = Kunc != nullptr;
+  if ((size_t)(h->np + 5 * h->NB) * 4 > 96 * 1024) { set_error("n too large for the LDS-resident solve vector"); delete h; return NNMPC_EINVAL; }
+  if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return NNMPC_EHIP; }
+  if (set_lds_attrs<128>() != 0 || set_lds_attrs<64>() != 0) {
+    set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP;
+  }
+
+  const int np = h->np, NB = h->NB, ka = h->ka, S = h->slots;
+  const size_t nb2 = (size_t)NB * NB;
+  int rc = 0;
+#define A_(ptr, cnt) if (!rc) rc = dev_alloc(h, &(ptr), (size_t)(cnt))
+  A_(h->Pt, h->tiles * nb2); A_(h->P32, (size_t)np * np); A_(h->P64, (size_t)np * np);
+  A_(h->tq64, (size_t)np * ka); A_(h->Kunc32, (size_t)np * ka);
+  A_(h->L, (size_t)S * h->tiles * nb2); A_(h->Y, (size_t)S * h->T * nb2);
+  QpDev& d = h->d;
+  const size_t V = (size_t)S * np;
+  A_(d.u, V); A_(d.zu, V); A_(d.zl, V); A_(d.lbv, V); A_(d.ubv, V); A_(d.q, V); A_(d.PU, V);
+  A_(d.rd, V); A_(d.rhs, V); A_(d.sol, V); A_(d.dua, V); A_(d.dvec, V); A_(d.mask, V); A_(d.uunc, V);
+  A_(d.x, V); A_(d.q64, V); A_(d.PX, V); A_(d.st, V);
+  A_(d.phase, S); A_(d.f_factor, S); A_(d.f_solve1, S); A_(d.f_solve2, S); A_(d.ipm_it, S);
+  A_(d.nfac, S); A_(d.prounds, S); A_(d.rcnt, S); A_(d.rconv, S); A_(d.newset, S); A_(d.fail, S);
+  A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
+  A_(d.u_out, (size_t)S * n); A_(d.act_out, (size_t)S * h->words); A_(d.status_out, S); A_(d.iters_out, 2 * S);
+  A_(h->x0_64, (size_t)S * ka); A_(h->x0_32, (size_t)S * ka);
+  A_(h->lb_d, (size_t)S * nu); A_(h->ub_d, (size_t)S * nu);
+  A_(h->in_stage, (size_t)S * n_aug);
+#undef A_
+  if (rc) { nnmpc_qp_destroy(h); return rc; }
+  d.n = n; d.np = np; d.nu = nu; d.slots = S; d.words = h->words;
+  d.max_ipm = o.max_ipm_iters; d.max_polish = o.max_polish_rounds; d.max_refine = o.max_refine;
+  d.ipm_tol = o.ipm_tol; d.refine_tol = o.refine_tol; d.bound_tol = o.bound_tol; d.stat_tol = 1e-8;
+
+  // host-side packing of the shared matrices (one-time setup)
+  std::vector<float> pt(h->tiles * nb2, 0.f), p32((size_t)np * np, 0.f), k32((size_t)np * ka, 0.f);
+  std::vector<double> p64((size_t)np * np, 0.0), t64((size_t)np * ka, 0.0);
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c <= r; ++c) {
+      const double v = P[(size_t)r * n + c];  // lower triangle is authoritative
+      p64[(size_t)r * np + c] = v; p64[(size_t)c * np + r] = v;
+      p32[(size_t)r * np + c] = (float)v; p32[(size_t)c * np + r] = (float)v;
+    }
+  for (int i = 0; i < h->T; ++i)
+    for (int j = 0; j <= i; ++j) {
+      float* t = pt.data() + ((size_t)i * (i + 1) / 2 + j) * nb2;
+      for (int r = 0; r < NB; ++r)
+        for (int c = 0; c < NB; ++c) {
+          const int gr = i * NB + r, gc = j * NB + c;
+          float v = 0.f;
+          if (gr < n && gc < n) v = (float)(gc <= gr ? P[(size_t)gr * n + gc] : P[(size_t)gc * n + gr]);
+          else if (gr == gc) v = 1.f;
+          t[(size_t)r * NB + c] = v;
+        }
+    }
+  for (int r = 0; r < n; ++r)
+    for (int k = 0; k < n_aug; ++k) {
+      t64[(size_t)r * ka + k] = tq[(size_t)r * n_aug + k];
+      if (Kunc) k32[(size_t)r * ka + k] = (float)Kunc[(size_t)r * n_aug + k];
+    }
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = hipMemcpy(h->Pt, pt.data(), pt.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->P32, p32.data(), p32.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->P64, p64.data(), p64.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->tq64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->Kunc32, k32.data(), k32.size() * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("upload of P/tq failed: %s", hipGetErrorString(e)); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
+  *out = h;
+  return NNMPC_OK;
+}
+
+int nnmpc_qp_destroy(nnmpc_qp* h) {
+  if (!h) return NNMPC_OK;
+  hipDeviceSynchronize();
+  for (void* p : h->allocs) hipFree(p);
+  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return NNMPC_OK;
+}
+
+int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on) {
+  if (!h) return NNMPC_EINVAL;
+  h->profiling = on != 0;
+  return NNMPC_OK;
+}
+
+int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
+  if (!h || !out) return NNMPC_EINVAL;
+  *out = h->stats;
+  if (reset) memset(&h->stats, 0, sizeof(h->stats));
+  return NNMPC_OK;
+}
+
+int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double* lb, const double* ub,
+                         double* u, uint32_t* active, int32_t* status, int32_t* iters, int32_t ptr_kind) {
+  if (!h || B < 0 || !x0 || !lb || !ub || !u) { set_error("nnmpc_qp_solve_batch: bad arguments"); return NNMPC_EINVAL; }
+  if (B == 0) return NNMPC_OK;
+  HIPCHK(hipSetDevice(h->device));
+  const int S = h->slots;
+  size_t e_tot0 = 0;
+  if (h->profiling) { e_tot0 = ev_get(h); hipEventRecord(h->ev_pool[e_tot0], h->stream); }
+  // device scratch for outputs when the caller hands host pointers
+  double* u_stage = nullptr; uint32_t* a_stage = nullptr; int32_t* s_stage = nullptr; int32_t* i_stage = nullptr;
+  if (ptr_kind == NNMPC_HOST) {
+    HIPCHK(hipMalloc((void**)&u_stage, (size_t)S * h->n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&a_stage, (size_t)S * h->words * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&s_stage, (size_t)S * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void**)&i_stage, (size_t)S * 2 * sizeof(int32_t)));
+  }
+  int rc = 0;
+  for (int b0 = 0; b0 < B && !rc; b0 += S) {
+    const int nb = std::min(S, B - b0);
+    const double *x0d, *lbd, *ubd;
+    double* ud; uint32_t* ad; int32_t* sd; int32_t* idv;
+    if (ptr_kind == NNMPC_HOST) {
+      HIPCHK(hipMemcpyAsync(h->in_stage, x0 + (size_t)b0 * h->n_aug, (size_t)nb * h->n_aug * 8, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->lb_d, lb + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(hipMemcpyAsync(h->ub_d, ub + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
+      x0d = h->in_stage; lbd = h->lb_d; ubd = h->ub_d;
+      ud = u_stage; ad = active ? a_stage : nullptr; sd = status ? s_stage : nullptr; idv = iters ? i_stage : nullptr;
+    } else {
+      x0d = x0 + (size_t)b0 * h->n_aug; lbd = lb + (size_t)b0 * h->nu; ubd = ub + (size_t)b0 * h->nu;
+      ud = u + (size_t)b0 * h->n;
+      ad = active ? active + (size_t)b0 * h->words : nullptr;
+      sd = status ? status + b0 : nullptr;
+      idv = iters ? iters + 2 * (size_t)b0 : nullptr;
+    }
+    rc = solve_wave(h, nb, x0d, lbd, ubd, ud, ad, sd, idv);
+    if (!rc && ptr_kind == NNMPC_HOST) {
+      HIPCHK(hipMemcpy(u + (size_t)b0 * h->n, u_stage, (size_t)nb * h->n * 8, hipMemcpyDeviceToHost));
+      if (active) HIPCHK(hipMemcpy(active + (size_t)b0 * h->words, a_stage, (size_t)nb * h->words * 4, hipMemcpyDeviceToHost));
+      if (status) HIPCHK(hipMemcpy(status + b0, s_stage, (size_t)nb * 4, hipMemcpyDeviceToHost));
+      if (iters) HIPCHK(hipMemcpy(iters + 2 * (size_t)b0, i_stage, (size_t)nb * 8, hipMemcpyDeviceToHost));
+    }
+  }
+  if (u_stage) hipFree(u_stage);
+  if (a_stage) hipFree(a_stage);
+  if (s_stage) hipFree(s_stage);
+  if (i_stage) hipFree(i_stage);
+  if (h->profiling) {
+    size_t e1 = ev_get(h);
+    hipEventRecord(h->ev_pool[e1], h->stream);
+    hipStreamSynchronize(h->stream);
+    h->ev_recs.push_back({3, e_tot0, e1, 0.0});
+    ev_collect(h);
+  }
+  return rc;
+}
+
+int nnmpc_qp_debug_factor_solve(nnmpc_qp* h, int32_t B, const float* dvec, const float* mask,
+                                const float* rhs, float* sol) {
+  if (!h || B <= 0 || B > h->slots || !dvec || !mask || !rhs || !sol) { set_error("debug_factor_solve: bad arguments"); return NNMPC_EINVAL; }
+  HIPCHK(hipSetDevice(h->device));
+  QpDev& d = h->d;
+  const int rows = ((B + 127) / 128) * 128;
+  std::vector<float> dv((size_t)rows * h->np, 0.f), mk((size_t)rows * h->np, 1.f), rh((size_t)rows * h->np, 0.f);
+  std::vector<int> fl(rows, 0);
+  for (int p = 0; p < B; ++p) {
+    fl[p] = 1;
+    for (int r = 0; r < h->n; ++r) {
+      dv[(size_t)p * h->np + r] = dvec[(size_t)p * h->n + r];
+      mk[(size_t)p * h->np + r] = mask[(size_t)p * h->n + r];
+      rh[(size_t)p * h->np + r] = rhs[(size_t)p * h->n + r];
+    }
+  }
+  HIPCHK(hipMemcpy(d.dvec, dv.data(), dv.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.mask, mk.data(), mk.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.rhs, rh.data(), rh.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.f_factor, fl.data(), rows * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(d.fail, 0, rows * 4));
+  factor_dispatch(h, rows, B);
+  solve_dispatch(h, rows, d.f_factor);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  std::vector<float> so((size_t)rows * h->np);
+  HIPCHK(hipMemcpy(so.data(), d.sol, so.size() * 4, hipMemcpyDeviceToHost));
+  for (int p = 0; p < B; ++p)
+    for (int r = 0; r < h->n; ++r) sol[(size_t)p * h->n + r] = so[(size_t)p * h->np + r];
+  if (h->profiling) { hipStreamSynchronize(h->stream); ev_collect(h); }
+  return NNMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""Batched box-constrained condensed QP on the GPU (host wrapper over the C ABI).
+
+    min 1/2 u'Pu + (tq x0)'u   s.t.  lb <= u_k <= ub,  k = 0..N-1
+
+is what DenseQPRegulator.solve hands to cvxopt.solvers.qp for a stable plant
+(reference lib/linearMPC.py:495-512 with G = tE, :476-482).  ``BatchedBoxQP``
+solves B of them per call in HIP kernels (see csrc/qp_solver.hip).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    """Pointer of a numpy array (host) or of anything exposing data_ptr() (device)."""
+    if a is None:
+        return None, None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr()), _lib.DEVICE
+    return a.ctypes.data_as(C.c_void_p), _lib.HOST
+
+
+class BatchedBoxQP:
+    """Owns the device copies of (P, tq) and the solver workspace.
+
+    P: (n, n) condensed Hessian (lower triangle read, as cvxopt does),
+    tq: (n, n_aug) so that q = tq @ x0, nu: inputs per stage (bounds are per
+    stage and tiled along the horizon like the reference's _get_h).
+    """
+
+    def __init__(self, P, tq, nu, *, Kunc="auto", max_batch=1024, nb=0, ipm_tol=0.0,
+                 max_rounds=0, max_ipm_iters=0, max_polish_rounds=0, max_refine=0):
+        lib = _lib.load()
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        tq = np.ascontiguousarray(tq, dtype=np.float64)
+        n, n_aug = tq.shape
+        if P.shape != (n, n) or n % nu:
+            raise ValueError("P must be (n, n), tq (n, n_aug), n a multiple of nu")
+        if isinstance(Kunc, str) and Kunc == "auto":
+            # warm-start gain u_unc = -P^-1 tq x0 (one-time host setup, like the
+            # reference's DARE/condensing in DenseQPRegulator.__init__)
+            import scipy.linalg as sla
+            Ps = np.tril(P) + np.tril(P, -1).T
+            Kunc = -sla.cho_solve(sla.cho_factor(Ps, lower=True), tq)
+        if Kunc is not None:
+            Kunc = np.ascontiguousarray(Kunc, dtype=np.float64)
+        self.n, self.n_aug, self.nu = n, n_aug, nu
+        self.words = (2 * n + 31) // 32
+        opts = _lib.QpOpts(max_batch=max_batch, nb=nb, max_ipm_iters=max_ipm_iters,
+                           max_polish_rounds=max_polish_rounds, max_refine=max_refine,
+                           max_rounds=max_rounds, ipm_tol=ipm_tol, refine_tol=0.0, bound_tol=0.0)
+        self._h = C.c_void_p()
+        kp = Kunc.ctypes.data_as(C.c_void_p) if Kunc is not None else None
+        _lib.check(lib.nnmpc_qp_create(C.byref(self._h), n, nu, n_aug,
+                                       P.ctypes.data_as(C.c_void_p), tq.ctypes.data_as(C.c_void_p),
+                                       kp, C.byref(opts)), "nnmpc_qp_create")
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nnmpc_qp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def solve_batch(self, x0, lb, ub):
+        """numpy in / numpy out.  x0 (B, n_aug), lb/ub (B, nu) or (nu,).
+
+        Returns dict(u (B, n), active (B, 2n) bool in the row order of the
+        reference's G, status (B,), ipm_iters (B,), factorizations (B,)).
+        """
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, self.n_aug)
+        B = x0.shape[0]
+        lb = np.ascontiguousarray(np.broadcast_to(np.asarray(lb, np.float64).reshape(-1, self.nu), (B, self.nu)))
+        ub = np.ascontiguousarray(np.broadcast_to(np.asarray(ub, np.float64).reshape(-1, self.nu), (B, self.nu)))
+        u = np.empty((B, self.n))
+        act = np.zeros((B, self.words), np.uint32)
+        status = np.empty(B, np.int32)
+        iters = np.empty((B, 2), np.int32)
+        _lib.check(self._lib.nnmpc_qp_solve_batch(
+            self._h, B, *(a.ctypes.data_as(C.c_void_p) for a in (x0, lb, ub, u, act, status, iters)),
+            _lib.HOST), "nnmpc_qp_solve_batch")
+        bits = np.unpackbits(act.view(np.uint8), axis=1, bitorder="little")[:, :2 * self.n].astype(bool)
+        return dict(u=u, active=bits, status=status, ipm_iters=iters[:, 0], factorizations=iters[:, 1])
+
+    def solve_batch_device(self, B, x0, lb, ub, u, active=None, status=None, iters=None):
+        """HBM-resident buffers (objects with data_ptr(), e.g. torch CUDA tensors, f64/u32/i32)."""
+        ptrs = [(_ptr(a)[0] if a is not None else None) for a in (x0, lb, ub, u, active, status, iters)]
+        _lib.check(self._lib.nnmpc_qp_solve_batch(self._h, B, *ptrs, _lib.DEVICE), "nnmpc_qp_solve_batch")
+
+    def set_profiling(self, on=True):
+        _lib.check(self._lib.nnmpc_qp_set_profiling(self._h, int(on)), "nnmpc_qp_set_profiling")
+
+    def stats(self, reset=False):
+        s = _lib.QpStats()
+        _lib.check(self._lib.nnmpc_qp_get_stats(self._h, C.byref(s), int(reset)), "nnmpc_qp_get_stats")
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def debug_factor_solve(self, dvec, mask, rhs):
+        """Kernel-level hook: solve (mask mask' o P + diag(dvec)) sol = rhs per row (f32)."""
+        dvec = np.ascontiguousarray(dvec, np.float32)
+        mask = np.ascontiguousarray(mask, np.float32)
+        rhs = np.ascontiguousarray(rhs, np.float32)
+        B = dvec.shape[0]
+        sol = np.empty((B, self.n), np.float32)
+        _lib.check(self._lib.nnmpc_qp_debug_factor_solve(
+            self._h, B, *(a.ctypes.data_as(C.c_void_p) for a in (dvec, mask, rhs, sol))),
+            "nnmpc_qp_debug_factor_solve")
+        return sol
