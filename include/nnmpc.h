@@ -58,10 +58,11 @@ typedef struct {
   int32_t nb;                /* Cholesky block 64 | 128; 0 = auto */
   int32_t max_ipm_iters;     /* 0 = 40 */
   int32_t max_polish_rounds; /* 0 = 12 */
-  int32_t max_refine;        /* refinement solves per active set; 0 = 10 */
+  int32_t max_refine;        /* PCG steps per active set; 0 = 60 */
   int32_t max_rounds;        /* lock-step rounds per wave; 0 = 120 */
-  float ipm_tol;             /* PDIP exit: |r_d|_inf <= tol*max(1,|q|_inf) and mu <= tol; 0 = 1e-3 */
-  double refine_tol;         /* |dx|_inf <= tol*max(1,|x|_inf); 0 = 1e-11 */
+  float ipm_tol;             /* PDIP exit, objective scaled by 1/median(diag P):
+                                |r_d|_inf and mu <= tol*max(1,|q|_inf); 0 = 1e-2 */
+  double refine_tol;         /* PCG exit: |step|_inf <= tol*max(1,|x|_inf); 0 = 1e-10 */
   double bound_tol;          /* primal feasibility slack of the KKT check; 0 = 1e-9 */
 } nnmpc_qp_opts;
 

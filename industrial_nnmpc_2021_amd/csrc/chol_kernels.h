@@ -10,9 +10,11 @@
 // GEMV with Y_j instead of substitutions.
 //
 // Step j of the factorisation (host loop, two launches):
-//   chol_diag_k : C = K[j,j] - sum_k L[j,k] L[j,k]'  (MFMA SYRK), potrf + trtri in LDS
+//   chol_diag_k : C = K[j,j] - Dacc[j], potrf + trtri in LDS  (Dacc[j] = sum_k L[j,k] L[j,k]'
+//                 was accumulated by the panel kernels of steps k < j)
 //   chol_panel_k: for every i > j:  L[i,j] = (K[i,j] - sum_k L[i,k] L[j,k]') Y_j'
-//                (two chained MFMA GEMMs, the second fed through LDS)
+//                (two chained MFMA GEMMs, the second fed through LDS), then
+//                Dacc[i] += L[i,j] L[i,j]'  (third MFMA product, same LDS image as A and B)
 #pragma once
 #include "tile_gemm.h"
 
@@ -26,6 +28,7 @@ struct CholArgs {
   const float* Pt;    // tile-packed lower P (pad diagonal = 1)
   float* L;           // [slots][tiles][NB*NB]
   float* Y;           // [slots][T][NB*NB]
+  float* Dacc;        // [slots][T][NB*NB] running sum_k L[i,k] L[i,k]' of every diagonal tile
   const float* dvec;  // [slots][np]
   const float* mask;  // [slots][np]
   const int* flag;    // [slots] factor this slot?
@@ -37,91 +40,198 @@ __device__ __forceinline__ size_t tile_off(int i, int j, int nb2) {
 }
 
 template <int NB>
-constexpr int chol_diag_lds_bytes() {
-  constexpr int a = TileCfg<NB>::LDS_FLOATS * 4;
-  constexpr int b = 2 * NB * (NB + 1) * 4;
-  return a > b ? a : b;
-}
-template <int NB>
 constexpr int chol_panel_lds_bytes() {
   return TileCfg<NB>::LDS_FLOATS * 4;
 }
 
+// ---- 32 x 32 building blocks of the diagonal-tile factorisation ----------------
+__device__ __forceinline__ float rdlane(float x, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
+// One wave; lane (l & 31) owns row (l & 31) of a 32 x 32 SPD block in a[0..31].
+// On exit a = its Cholesky factor (entries right of the diagonal are garbage) and
+// y = column (l & 31) of the inverse factor.  Pivot rows travel by v_readlane.
+__device__ __forceinline__ int potrf_trtri_32(float (&a)[32], float (&y)[32], int col) {
+  int bad = 0;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    float d = rdlane(a[c], c);
+    if (!(d > 1e-30f)) { d = 1e-30f; bad = 1; }
+    const float inv = 1.0f / sqrtf(d);
+    const float lc = a[c] * inv;
+    a[c] = lc;
+#pragma unroll
+    for (int cc = c + 1; cc < 32; ++cc) a[cc] -= lc * rdlane(lc, cc);
+  }
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    float s = (r == col) ? 1.f : 0.f;
+#pragma unroll
+    for (int m = 0; m < r; ++m) s -= rdlane(a[m], r) * y[m];
+    y[r] = s / rdlane(a[r], r);
+  }
+  return bad;
+}
+
+// 32x32x32 products on LDS operands (one wave).  A is read as rows [r][k]
+// (ds_read_b128).  B is read either as rows [c][k] (NT) or as [k][c] (NN).
+__device__ __forceinline__ f32x16 mma32_nt(const float* A, int lda, const float* B, int ldb, int lane,
+                                           f32x16 acc) {
+  const int lr = lane & 31, kh = (lane >> 5) * 16;
+  f32x4 a4[4], b4[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    a4[v] = *reinterpret_cast<const f32x4*>(A + lr * lda + kh + 4 * v);
+    b4[v] = *reinterpret_cast<const f32x4*>(B + lr * ldb + kh + 4 * v);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v][e], b4[v][e], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 mma32_nn(const float* A, int lda, const float* Bt, int ldb, int lane,
+                                           f32x16 acc) {
+  const int lr = lane & 31, kh = (lane >> 5) * 16;
+  f32x4 a4[4];
+  float b[16];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const f32x4*>(A + lr * lda + kh + 4 * v);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) b[k] = Bt[(kh + k) * ldb + lr];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[v][e], b[4 * v + e], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+template <int NB>
+constexpr int chol_diag_lds_bytes() {
+  return (2 * NB * (NB + 4) + 4 * 32 * 36) * 4;
+}
+
+// Diagonal tile of step j:  C = K[j,j] - Dacc[j];  L_jj = chol(C);  Y_j = L_jj^-1.
+// Blocked with 32 x 32 sub-blocks, all in LDS (row stride NB+4: 16-B aligned rows,
+// conflict-free ds_read_b128 operand reads): sub-block potrf + trtri in the
+// registers of wave 0, TRSM / SYRK / assembly of the inverse on MFMA by all waves.
 template <int NB>
 __global__ __launch_bounds__(256) void chol_diag_k(CholArgs a, int j) {
   const int p = blockIdx.x;
   if (!a.flag[p]) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  using C = TileCfg<NB>;
-  constexpr int S = NB + 1;
+  constexpr int LD = NB + 4;
+  constexpr int NS = NB / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
   float* Lp = a.L + (size_t)p * a.tiles * NB * NB;
-
-  f32x16 acc[C::MT][C::MT];
-  zero_acc<NB>(acc);
-  TileRowOp<NB> A{Lp + tile_off(j, 0, NB * NB)};
-  tile_gemm_nt<NB>(acc, A, A, j * NB, lds, true);
-
-  // C = mask mask' o P[j,j] + diag(dvec) - acc  -> LDS [NB][NB+1]
   float* Cs = lds;
-  float* Ys = lds + NB * S;
+  float* Ys = lds + NB * LD;
+  float* Ts = Ys + NB * LD + wave * 32 * 36;   // per-wave 32 x 32 scratch (stride 36)
+
   const float* Pjj = a.Pt + tile_off(j, j, NB * NB);
+  float* Dj = a.Dacc + ((size_t)p * a.T + j) * NB * NB;
   const float* mk = a.mask + (size_t)p * a.np + j * NB;
   const float* dv = a.dvec + (size_t)p * a.np + j * NB;
+  for (int e4 = tid; e4 < NB * NB / 4; e4 += 256) {
+    const int row = (4 * e4) / NB, col = (4 * e4) % NB;
+    const f32x4 pv = *reinterpret_cast<const f32x4*>(Pjj + 4 * e4);
+    const f32x4 dd = *reinterpret_cast<const f32x4*>(Dj + 4 * e4);
+    const f32x4 mc = *reinterpret_cast<const f32x4*>(mk + col);
+    const float mr = mk[row];
+    f32x4 v;
 #pragma unroll
-  for (int mi = 0; mi < C::MT; ++mi)
+    for (int e = 0; e < 4; ++e) {
+      v[e] = mr * mc[e] * pv[e] - dd[e];
+      if (row == col + e) v[e] += dv[row];
+    }
+    *reinterpret_cast<f32x4*>(Cs + row * LD + col) = v;
+    *reinterpret_cast<f32x4*>(Ys + row * LD + col) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(Dj + 4 * e4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+
+  for (int s = 0; s < NS; ++s) {
+    if (wave == 0) {
+      const int r = lane & 31;
+      float av[32], yv[32];
+      const float* src = Cs + (32 * s + r) * LD + 32 * s;
 #pragma unroll
-    for (int mj = 0; mj < C::MT; ++mj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
-        const int col = wc * C::WT + mj * 32 + acc_col(lane);
-        float v = mk[row] * mk[col] * Pjj[row * NB + col] - acc[mi][mj][r];
-        if (row == col) v += dv[row];
-        Cs[row * S + col] = v;
+      for (int v = 0; v < 8; ++v) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * v);
+        av[4 * v] = t[0]; av[4 * v + 1] = t[1]; av[4 * v + 2] = t[2]; av[4 * v + 3] = t[3];
       }
-  __syncthreads();
-
-  // ---- potrf (right-looking, in LDS)
-  int bad = 0;
-  for (int c = 0; c < NB; ++c) {
-    float piv = Cs[c * S + c];
-    if (!(piv > 1e-30f)) { piv = 1e-30f; bad = 1; }
-    const float sq = sqrtf(piv);
-    const float inv = 1.0f / sq;
-    for (int r = c + 1 + tid; r < NB; r += 256) Cs[r * S + c] *= inv;
+#pragma unroll
+      for (int m = 0; m < 32; ++m) yv[m] = 0.f;
+      const int bad = potrf_trtri_32(av, yv, r);
+      if (lane < 32) {
+        float* dst = Cs + (32 * s + r) * LD + 32 * s;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dst[c] = (c <= r) ? av[c] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 32; ++rr) Ys[(32 * s + rr) * LD + 32 * s + r] = yv[rr];
+        if (bad && lane == 0) a.fail[p] = 1;
+      }
+    }
     __syncthreads();
-    if (tid == 0) Cs[c * S + c] = sq;
-    for (int r = c + 1 + wave; r < NB; r += 4) {
-      const float lrc = Cs[r * S + c];
-      for (int cc = c + 1 + lane; cc <= r; cc += 64) Cs[r * S + cc] -= lrc * Cs[cc * S + c];
+    // TRSM: C[i,s] <- C[i,s] Y_ss'   (one sub-block per wave)
+    for (int i = s + 1 + wave; i < NS; i += 4) {
+      f32x16 acc = mma32_nt(Cs + 32 * i * LD + 32 * s, LD, Ys + 32 * s * LD + 32 * s, LD, lane, zero16());
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Cs[(32 * i + acc_row(r, lane)) * LD + 32 * s + acc_col(lane)] = acc[r];
+    }
+    __syncthreads();
+    // SYRK: C[i,k] -= L[i,s] L[k,s]'  for s < k <= i
+    {
+      int b = 0;
+      for (int i = s + 1; i < NS; ++i)
+        for (int k = s + 1; k <= i; ++k, ++b) {
+          if ((b & 3) != wave) continue;
+          f32x16 acc = mma32_nt(Cs + 32 * i * LD + 32 * s, LD, Cs + 32 * k * LD + 32 * s, LD, lane, zero16());
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Cs[(32 * i + acc_row(r, lane)) * LD + 32 * k + acc_col(lane)] -= acc[r];
+        }
     }
     __syncthreads();
   }
-  if (bad && tid == 0) a.fail[p] = 1;
 
-  // ---- write L[j,j] (strict upper zeroed)
+  // ---- write L[j,j] (strictly upper part zeroed)
   float* Ljj = Lp + tile_off(j, j, NB * NB);
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    Ljj[e] = (c <= r) ? Cs[r * S + c] : 0.f;
+  for (int e4 = tid; e4 < NB * NB / 4; e4 += 256) {
+    const int row = (4 * e4) / NB, col = (4 * e4) % NB;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LD + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (col + e > row) v[e] = 0.f;
+    *reinterpret_cast<f32x4*>(Ljj + 4 * e4) = v;
   }
 
-  // ---- trtri: column c of Y = L^-1 by forward substitution (thread c)
-  if (tid < NB) {
-    const int c = tid;
-    for (int r = 0; r < NB; ++r) {
-      float s = (r == c) ? 1.f : 0.f;
-      for (int m = 0; m < r; ++m) s -= Cs[r * S + m] * Ys[m * S + c];
-      Ys[r * S + c] = (r >= c) ? s / Cs[r * S + r] : 0.f;
+  // ---- assemble Y = L^-1 below the diagonal sub-blocks, distance d = i - k at a time:
+  //      Y[i,k] = -Y[i,i] * sum_{m=k}^{i-1} L[i,m] Y[m,k]
+  for (int d = 1; d < NS; ++d) {
+    for (int i = d + wave; i < NS; i += 4) {
+      const int k = i - d;
+      f32x16 t = zero16();
+      for (int m = k; m < i; ++m)
+        t = mma32_nn(Cs + 32 * i * LD + 32 * m, LD, Ys + 32 * m * LD + 32 * k, LD, lane, t);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ts[acc_row(r, lane) * 36 + acc_col(lane)] = t[r];
+      // same wave wrote Ts; LDS ops of one wave complete in order
+      f32x16 y = mma32_nn(Ys + 32 * i * LD + 32 * i, LD, Ts, 36, lane, zero16());
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ys[(32 * i + acc_row(r, lane)) * LD + 32 * k + acc_col(lane)] = -y[r];
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* Yj = a.Y + ((size_t)p * a.T + j) * NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    Yj[e] = Ys[r * S + c];
+  for (int e4 = tid; e4 < NB * NB / 4; e4 += 256) {
+    const int row = (4 * e4) / NB, col = (4 * e4) % NB;
+    *reinterpret_cast<f32x4*>(Yj + 4 * e4) = *reinterpret_cast<const f32x4*>(Ys + row * LD + col);
   }
 }
 
@@ -148,6 +258,28 @@ __device__ __forceinline__ void second_gemm_chunk(
   store_chunk<NB>(rb, sB, tid);
   __syncthreads();
   mma_chunk<NB>(out, sA, sB, wr, wc, lane);
+  __syncthreads();
+}
+
+// One K-chunk of  S += X X'  with X (NB x NB) held in accumulators: columns
+// MC*32.. of X are staged once and used as both MFMA operands.
+template <int NB, int MC>
+__device__ __forceinline__ void syrk_chunk(const f32x16 (&x)[TileCfg<NB>::MT][TileCfg<NB>::MT],
+                                           f32x16 (&s)[TileCfg<NB>::MT][TileCfg<NB>::MT], float* sA,
+                                           int wr, int wc, int lane) {
+  using C = TileCfg<NB>;
+  constexpr int WT = C::WT;
+  constexpr int NEED_WC = (MC * 32) / WT;
+  constexpr int MJ = ((MC * 32) % WT) / 32;
+  if (wc == NEED_WC) {
+#pragma unroll
+    for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sA[(wr * WT + mi * 32 + acc_row(r, lane)) * LDS_LD + acc_col(lane)] = x[mi][MJ][r];
+  }
+  __syncthreads();
+  mma_chunk<NB>(s, sA, sA, wr, wc, lane);
   __syncthreads();
 }
 
@@ -206,6 +338,26 @@ __global__ __launch_bounds__(256) void chol_panel_k(CholArgs a, int j) {
         const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
         const int col = wc * C::WT + mj * 32 + acc_col(lane);
         Lij[row * NB + col] = out[mi][mj][r];
+      }
+
+  // Dacc[i] += L[i,j] L[i,j]'   (the diagonal tile's update, done while the tile is on chip)
+  zero_acc<NB>(acc);
+  syrk_chunk<NB, 0>(out, acc, sA, wr, wc, lane);
+  syrk_chunk<NB, 1>(out, acc, sA, wr, wc, lane);
+  if constexpr (NB == 128) {
+    syrk_chunk<NB, 2>(out, acc, sA, wr, wc, lane);
+    syrk_chunk<NB, 3>(out, acc, sA, wr, wc, lane);
+  }
+  float* Di = a.Dacc + ((size_t)p * a.T + i) * NB * NB;
+#pragma unroll
+  for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+    for (int mj = 0; mj < C::MT; ++mj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
+        const int col = wc * C::WT + mj * 32 + acc_col(lane);
+        Di[row * NB + col] += acc[mi][mj][r];
       }
 }
 

@@ -33,22 +33,24 @@ using namespace nnmpc;
 namespace {
 
 enum { PH_INIT = 0, PH_IPM = 1, PH_POLISH = 2, PH_DONE = 3 };
+enum { PS_START = 0, PS_CG = 1, PS_CHECK = 2 };
 enum { CNT_ACTIVE = 0, CNT_FACTOR = 1, CNT_IPM = 2, CNT_POLISH = 3, CNT_SOLVE1 = 4, CNT_PS1 = 5 };
 
 struct QpDev {
   int n, np, nu, slots;
   int max_ipm, max_polish, max_refine;
-  float ipm_tol;
-  double refine_tol, bound_tol, stat_tol;
+  float ipm_tol, delta;
+  double refine_tol, bound_tol, stat_tol, pscale;
+  const float* pdiag;  // [np] diagonal of the normalised P
   // f32 [slots][np]
   float *u, *zu, *zl, *lbv, *ubv, *q, *PU, *rd, *rhs, *sol, *dua, *dvec, *mask, *uunc;
   // f64 [slots][np]
-  double *x, *q64, *PX;
+  double *x, *q64, *PX, *r64, *p64, *v64;   // PX = P64 * v64
   unsigned char* st;  // [slots][np]  0 free, 1 at upper, 2 at lower
   const double *lb64, *ub64;  // [slots][nu]
-  int *phase, *f_factor, *f_solve1, *f_solve2, *ipm_it, *nfac, *prounds, *rcnt, *rconv, *newset,
-      *fail;
+  int *phase, *f_factor, *f_solve1, *f_solve2, *ipm_it, *nfac, *prounds, *rcnt, *psub, *fail;
   float *mu, *gap, *smu, *qscale;
+  double* rz;
   int* counters;
   double* u_out;       // [slots][n]
   uint32_t* act_out;   // [slots][words]
@@ -91,6 +93,13 @@ __device__ double block_maxd(double v, double* sh) {
   __syncthreads();
   return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
+__device__ double block_sumd(double v, double* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
 __device__ int block_sum_i(int v, int* sh) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __syncthreads();
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256) void init_k(QpDev d, int nprob) {
   const size_t o = (size_t)p * d.np;
   if (p >= nprob) {  // unused slot of this wave
     if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
-    for (int r = tid; r < d.np; r += 256) { d.u[o + r] = 0.f; d.x[o + r] = 0.0; }
+    for (int r = tid; r < d.np; r += 256) { d.u[o + r] = 0.f; d.x[o + r] = 0.0; d.v64[o + r] = 0.0; }
     return;
   }
   float qm = 0.f;
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256) void init_k(QpDev d, int nprob) {
     if (r < d.n) {
       const int c = r % d.nu;
       const float lb = (float)d.lb64[(size_t)p * d.nu + c], ub = (float)d.ub64[(size_t)p * d.nu + c];
-      const float q = (float)d.q64[o + r];
+      const float q = (float)(d.q64[o + r] / d.pscale);
       const float w = ub - lb;
       float u0 = d.uunc[o + r];
       u0 = fminf(fmaxf(u0, lb + 0.05f * w), ub - 0.05f * w);
@@ -129,14 +138,15 @@ __global__ __launch_bounds__(256) void init_k(QpDev d, int nprob) {
     }
     d.mask[o + r] = 1.f; d.dvec[o + r] = 0.f; d.rhs[o + r] = 0.f; d.sol[o + r] = 0.f;
     d.dua[o + r] = 0.f; d.rd[o + r] = 0.f; d.x[o + r] = 0.0; d.st[o + r] = 0;
+    d.r64[o + r] = 0.0; d.p64[o + r] = 0.0; d.v64[o + r] = 0.0;
   }
   qm = block_max(qm, shf);
   if (tid == 0) {
     d.qscale[p] = fmaxf(1.f, qm);
     d.phase[p] = PH_INIT;
     d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
-    d.ipm_it[p] = d.nfac[p] = d.prounds[p] = d.rcnt[p] = d.rconv[p] = d.newset[p] = d.fail[p] = 0;
-    d.mu[p] = d.gap[p] = d.smu[p] = 0.f;
+    d.ipm_it[p] = d.nfac[p] = d.prounds[p] = d.rcnt[p] = d.psub[p] = d.fail[p] = 0;
+    d.mu[p] = d.gap[p] = d.smu[p] = 0.f; d.rz[p] = 0.0;
   }
 }
 
@@ -162,6 +172,72 @@ __device__ void write_outputs(const QpDev& d, int p, int status) {
     d.iters_out[2 * p] = d.ipm_it[p];
     d.iters_out[2 * p + 1] = d.nfac[p];
   }
+}
+
+// Preconditioned CG on the free block  P_FF x_F = -(q + P_FA x_A)_F  in f64, the
+// f32 Cholesky of the masked, regularised P being the preconditioner M.
+// cg_alpha: needs PX = P p.   x += a p, r -= a P p;  returns 1 if another
+// preconditioner solve is wanted (rhs = r), 0 if converged (psub -> CHECK, v = x).
+__device__ int cg_alpha(const QpDev& d, int p, double* shd) {
+  const int tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  double pap = 0.0;
+  for (int r = tid; r < d.n; r += 256)
+    if (d.st[o + r] == 0) pap += d.p64[o + r] * d.PX[o + r];
+  pap = block_sumd(pap, shd);
+  const double rz = d.rz[p];
+  const bool ok = (pap > 0.0) && (rz > 0.0);
+  const double a = ok ? rz / pap : 0.0;
+  double pm = 0.0, xm = 0.0;
+  for (int r = tid; r < d.n; r += 256) {
+    if (d.st[o + r] == 0) {
+      const double pv = d.p64[o + r];
+      const double x = d.x[o + r] + a * pv;
+      d.x[o + r] = x;
+      d.r64[o + r] -= a * d.PX[o + r];
+      pm = fmax(pm, fabs(pv));
+      xm = fmax(xm, fabs(x));
+    } else {
+      xm = fmax(xm, fabs(d.x[o + r]));
+    }
+  }
+  pm = block_maxd(pm, shd);
+  xm = block_maxd(xm, shd);
+  const int rc = d.rcnt[p] + 1;
+  const bool nan = !(a == a) || !(xm == xm);
+  const bool conv = !ok || nan || (fabs(a) * pm <= d.refine_tol * fmax(1.0, xm)) || rc >= d.max_refine;
+  if (conv) {
+    for (int r = tid; r < d.n; r += 256) d.v64[o + r] = d.x[o + r];
+  } else {
+    for (int r = tid; r < d.n; r += 256) d.rhs[o + r] = d.st[o + r] ? 0.f : (float)d.r64[o + r];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    d.rcnt[p] = rc;
+    if (nan) d.fail[p] = 1;
+    if (conv) d.psub[p] = PS_CHECK;
+  }
+  return conv ? 0 : 1;
+}
+// cg_beta: needs sol = M^-1 r.   p = z + (r'z / rz_old) p,  v = p.
+__device__ void cg_beta(const QpDev& d, int p, double* shd) {
+  const int tid = threadIdx.x;
+  const size_t o = (size_t)p * d.np;
+  double rzn = 0.0;
+  for (int r = tid; r < d.n; r += 256)
+    if (d.st[o + r] == 0) rzn += d.r64[o + r] * (double)d.sol[o + r];
+  rzn = block_sumd(rzn, shd);
+  const bool first = d.psub[p] == PS_START;
+  const double rz = d.rz[p];
+  const double beta = (first || !(rz > 0.0)) ? 0.0 : rzn / rz;
+  for (int r = tid; r < d.n; r += 256) {
+    double pv = 0.0;
+    if (d.st[o + r] == 0) pv = (double)d.sol[o + r] + beta * d.p64[o + r];
+    d.p64[o + r] = pv;
+    d.v64[o + r] = pv;
+  }
+  __syncthreads();
+  if (tid == 0) { d.rz[p] = rzn; d.psub[p] = PS_CG; }
 }
 
 // Round stage 1: needs PU = P u (f32) for INIT/IPM slots, PX = P x (f64) for POLISH slots.
@@ -206,12 +282,12 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
     const float mu = gs / (2.f * n);
     const int it = d.ipm_it[p];
     const bool nan = !(rdm == rdm) || !(gs == gs);
-    const bool conv = (rdm <= d.ipm_tol * d.qscale[p] && mu <= d.ipm_tol) || it >= d.max_ipm || nan;
+    const bool conv = (rdm <= d.ipm_tol * d.qscale[p] && mu <= d.ipm_tol * d.qscale[p]) || it >= d.max_ipm || nan;
     if (!conv) {
       for (int r = tid; r < n; r += 256) {
         const float u = d.u[o + r], zu = d.zu[o + r], zl = d.zl[o + r];
         const float su = fmaxf(d.ubv[o + r] - u, SLACK_MIN), sl = fmaxf(u - d.lbv[o + r], SLACK_MIN);
-        d.dvec[o + r] = zu / su + zl / sl;
+        d.dvec[o + r] = zu / su + zl / sl + d.delta;
         d.mask[o + r] = 1.f;
         d.rhs[o + r] = -(d.PU[o + r] + d.q[o + r]);
       }
@@ -232,26 +308,30 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
       const int c = r % d.nu;
       int s = 0;
       if (!nan) {
-        const bool au = zu > su, al = zl > sl;
+        const float pd = d.pdiag[r];
+        const bool au = zu > pd * su, al = zl > pd * sl;
         if (au && al) s = (zu * sl > zl * su) ? 1 : 2; else if (au) s = 1; else if (al) s = 2;
       }
       d.st[o + r] = (unsigned char)s;
-      d.x[o + r] = s == 1 ? d.ub64[(size_t)p * d.nu + c]
-                 : s == 2 ? d.lb64[(size_t)p * d.nu + c]
-                          : (nan ? 0.0 : (double)u);
+      const double xv = s == 1 ? d.ub64[(size_t)p * d.nu + c]
+                      : s == 2 ? d.lb64[(size_t)p * d.nu + c]
+                               : (nan ? 0.0 : (double)u);
+      d.x[o + r] = xv;
+      d.v64[o + r] = xv;
     }
     if (tid == 0) {
       if (nan) d.fail[p] = 1;
-      d.phase[p] = PH_POLISH; d.newset[p] = 1; d.rcnt[p] = 0; d.rconv[p] = 0; d.prounds[p] = 0;
+      d.phase[p] = PH_POLISH; d.psub[p] = PS_START; d.rcnt[p] = 0; d.prounds[p] = 0;
       d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
       atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
     }
     return;
   }
 
-  // ---- PH_POLISH: g = P x + q in f64
-  if (d.rconv[p]) {
-    // KKT check on the refined point
+  // ---- PH_POLISH (PX = P64 * v64, v = x in START / CHECK, v = p in CG)
+  const int sub = d.psub[p];
+  if (sub == PS_CHECK) {
+    // KKT check on the refined point, g = P x + q in f64
     int bad = 0;
     double gfree = 0.0;
     for (int r = tid; r < n; r += 256) {
@@ -267,7 +347,8 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
     gfree = block_maxd(gfree, shd);
     if (bad == 0) {
       // stationarity of the free block certifies the refinement itself
-      write_outputs(d, p, gfree <= d.stat_tol * (double)d.qscale[p] ? NNMPC_ST_OPTIMAL : NNMPC_ST_MAXITER);
+      const double gs = d.pscale * (double)d.qscale[p];
+      write_outputs(d, p, gfree <= d.stat_tol * gs ? NNMPC_ST_OPTIMAL : NNMPC_ST_MAXITER);
       if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
       return;
     }
@@ -282,57 +363,48 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
       const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
       const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
       const int s = d.st[o + r];
+      double xn = x;
       if (s == 0) {
-        if (x > ub + d.bound_tol) { d.st[o + r] = 1; d.x[o + r] = ub; }
-        else if (x < lb - d.bound_tol) { d.st[o + r] = 2; d.x[o + r] = lb; }
+        if (x > ub + d.bound_tol) { d.st[o + r] = 1; xn = ub; }
+        else if (x < lb - d.bound_tol) { d.st[o + r] = 2; xn = lb; }
       } else if ((s == 1 && g >= 0.0) || (s == 2 && g <= 0.0)) {
         d.st[o + r] = 0;
       }
+      d.x[o + r] = xn;
+      d.v64[o + r] = xn;
     }
     if (tid == 0) {
-      d.prounds[p] = pr; d.newset[p] = 1; d.rcnt[p] = 0; d.rconv[p] = 0;
-      d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;  // P x is stale: re-solve next round
+      d.prounds[p] = pr; d.psub[p] = PS_START; d.rcnt[p] = 0;
+      d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;  // P x is stale: restart next round
       atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
     }
     return;
   }
-  // refinement solve:  K_FF dx_F = -(P x + q)_F
-  const int ns = d.newset[p];
-  for (int r = tid; r < n; r += 256) {
-    const int s = d.st[o + r];
-    d.rhs[o + r] = s ? 0.f : (float)(-(d.PX[o + r] + d.q64[o + r]));
-    if (ns) { d.mask[o + r] = s ? 0.f : 1.f; d.dvec[o + r] = s ? 1.f : 0.f; }
-  }
-  if (tid == 0) {
-    d.f_factor[p] = ns; d.f_solve1[p] = 1; d.f_solve2[p] = 0;
-    if (ns) { d.nfac[p] += 1; d.newset[p] = 0; atomicAdd(&d.counters[CNT_FACTOR], 1); }
-    atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
-    atomicAdd(&d.counters[CNT_SOLVE1], 1); atomicAdd(&d.counters[CNT_PS1], 1);
-  }
-}
-
-// x += dx, decide whether the refinement has converged (shared by mid / post).
-__device__ void polish_update(const QpDev& d, int p, double* shd) {
-  const int tid = threadIdx.x;
-  const size_t o = (size_t)p * d.np;
-  double dxm = 0.0, xm = 0.0;
-  for (int r = tid; r < d.n; r += 256) {
-    if (d.st[o + r] == 0) {
-      const double dx = (double)d.sol[o + r];
-      const double x = d.x[o + r] + dx;
-      d.x[o + r] = x;
-      dxm = fmax(dxm, fabs(dx));
-      xm = fmax(xm, fabs(x));
+  if (sub == PS_START) {
+    // new active set: r = -(P x + q)_F, factor the masked (regularised) P, z = M^-1 r
+    for (int r = tid; r < n; r += 256) {
+      const int s = d.st[o + r];
+      const double rr = s ? 0.0 : -(d.PX[o + r] + d.q64[o + r]);
+      d.r64[o + r] = rr;
+      d.rhs[o + r] = (float)rr;
+      d.mask[o + r] = s ? 0.f : 1.f;
+      d.dvec[o + r] = s ? 1.f : d.delta;
     }
+    if (tid == 0) {
+      d.f_factor[p] = 1; d.f_solve1[p] = 1; d.f_solve2[p] = 0;
+      d.nfac[p] += 1;
+      atomicAdd(&d.counters[CNT_FACTOR], 1);
+      atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
+      atomicAdd(&d.counters[CNT_SOLVE1], 1); atomicAdd(&d.counters[CNT_PS1], 1);
+    }
+    return;
   }
-  dxm = block_maxd(dxm, shd);
-  xm = block_maxd(xm, shd);
+  // PS_CG: PX = P p
+  const int go = cg_alpha(d, p, shd);
   if (tid == 0) {
-    const int rc = d.rcnt[p] + 1;
-    d.rcnt[p] = rc;
-    const bool nan = !(dxm == dxm);
-    if (nan) d.fail[p] = 1;
-    d.rconv[p] = (dxm <= d.refine_tol * fmax(1.0, xm)) || rc >= d.max_refine || nan;
+    d.f_factor[p] = 0; d.f_solve1[p] = go; d.f_solve2[p] = 0;
+    atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
+    if (go) { atomicAdd(&d.counters[CNT_SOLVE1], 1); atomicAdd(&d.counters[CNT_PS1], 1); }
   }
 }
 
@@ -345,9 +417,8 @@ __global__ __launch_bounds__(256) void stage_mid_k(QpDev d) {
   if (!d.f_solve1[p]) return;
   const int ph = d.phase[p], n = d.n;
   if (ph == PH_POLISH) {
-    polish_update(d, p, shd);
-    __syncthreads();
-    if (tid == 0) d.f_solve2[p] = !d.rconv[p];
+    cg_beta(d, p, shd);
+    if (tid == 0) d.f_solve2[p] = 1;   // second CG half-step of this round
     return;
   }
   // IPM: affine (predictor) direction -> sigma -> corrector right-hand side
@@ -384,11 +455,11 @@ __global__ __launch_bounds__(256) void stage_mid_k(QpDev d) {
 // Round stage 2b: polish slots that take a second refinement solve this round
 // (PX was recomputed from the updated x).
 __global__ __launch_bounds__(256) void stage_mid2_k(QpDev d) {
+  __shared__ double shd[4];
   const int p = blockIdx.x, tid = threadIdx.x;
-  const size_t o = (size_t)p * d.np;
   if (d.phase[p] != PH_POLISH || !d.f_solve1[p] || !d.f_solve2[p]) return;
-  for (int r = tid; r < d.n; r += 256)
-    d.rhs[o + r] = d.st[o + r] ? 0.f : (float)(-(d.PX[o + r] + d.q64[o + r]));
+  const int go = cg_alpha(d, p, shd);
+  if (tid == 0) d.f_solve2[p] = go;
 }
 
 // Round stage 3 (after solve #2).
@@ -399,7 +470,7 @@ __global__ __launch_bounds__(256) void stage_post_k(QpDev d) {
   const size_t o = (size_t)p * d.np;
   if (!d.f_solve2[p]) return;
   const int ph = d.phase[p], n = d.n;
-  if (ph == PH_POLISH) { polish_update(d, p, shd); return; }
+  if (ph == PH_POLISH) { cg_beta(d, p, shd); return; }
   const float smu = d.smu[p];
   float t = 0.f;
   for (int r = tid; r < n; r += 256) {
@@ -471,9 +542,12 @@ struct nnmpc_qp {
   double* P64;    // full np x np, f64
   double* tq64;   // np x ka
   float* Kunc32;  // np x ka
+  float* pdiag;   // np, diagonal of P / pscale
+  double pscale;  // median diag(P): the f32 PDIP works on P / pscale, q / pscale
   // per-slot workspace
   float* L;
   float* Y;
+  float* Dacc;
   QpDev d;
   double *x0_64;  // [slots][ka]
   float* x0_32;
@@ -573,7 +647,7 @@ template <int NB>
 void factor_all(nnmpc_qp* h, int nslots, int nfactor) {
   CholArgs a;
   a.n = h->n; a.np = h->np; a.T = h->T; a.tiles = h->tiles;
-  a.Pt = h->Pt; a.L = h->L; a.Y = h->Y; a.dvec = h->d.dvec; a.mask = h->d.mask;
+  a.Pt = h->Pt; a.L = h->L; a.Y = h->Y; a.Dacc = h->Dacc; a.dvec = h->d.dvec; a.mask = h->d.mask;
   a.flag = h->d.f_factor; a.fail = h->d.fail;
   const double nb = NB;
   for (int j = 0; j < h->T; ++j) {
@@ -584,7 +658,8 @@ void factor_all(nnmpc_qp* h, int nslots, int nfactor) {
     const int below = h->T - 1 - j;
     if (below > 0) {
       // algorithmic flops of this launch: per tile 2 NB^2 (j NB) update + NB^3 triangular solve
-      const double fl = (double)nfactor * below * (2.0 * nb * nb * (j * nb) + nb * nb * nb);
+      // + NB^3 symmetric rank-NB update of the diagonal tile
+      const double fl = (double)nfactor * below * (2.0 * nb * nb * (j * nb) + nb * nb * nb + nb * nb * nb);
       EvScope es(h, 0, fl);
       hipLaunchKernelGGL((chol_panel_k<NB>), dim3(below, nslots), dim3(256), chol_panel_lds_bytes<NB>(), h->stream, a, j);
     }
@@ -627,7 +702,7 @@ int solve_wave(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_de
   for (; round < h->opts.max_rounds; ++round) {
     HIPCHK(hipMemsetAsync(d.counters, 0, 8 * sizeof(int), s));
     if (any_ipm) gemm32(h, d.PU, h->np, d.u, h->np, h->P32, h->np, rows, h->np, h->np);
-    if (any_polish) gemm64(h, d.PX, h->np, d.x, h->np, h->P64, h->np, rows, h->np, h->np);
+    if (any_polish) gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np);
     hipLaunchKernelGGL(stage_pre_k, dim3(rows), dim3(256), 0, s, d);
     HIPCHK(hipMemcpyAsync(cnt, d.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -642,7 +717,7 @@ int solve_wave(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_de
       solve_dispatch(h, rows, d.f_solve1);
       hipLaunchKernelGGL(stage_mid_k, dim3(rows), dim3(256), 0, s, d);
       if (cnt[CNT_PS1] > 0) {
-        gemm64(h, d.PX, h->np, d.x, h->np, h->P64, h->np, rows, h->np, h->np);
+        gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np);
         hipLaunchKernelGGL(stage_mid2_k, dim3(rows), dim3(256), 0, s, d);
       }
       solve_dispatch(h, rows, d.f_solve2);
@@ -688,10 +763,10 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.nb != 64 && o.nb != 128) { set_error("nb must be 64 or 128"); delete h; return NNMPC_EINVAL; }
   if (o.max_ipm_iters <= 0) o.max_ipm_iters = 40;
   if (o.max_polish_rounds <= 0) o.max_polish_rounds = 12;
-  if (o.max_refine <= 0) o.max_refine = 10;
+  if (o.max_refine <= 0) o.max_refine = 60;
   if (o.max_rounds <= 0) o.max_rounds = 120;
-  if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-3f;
-  if (o.refine_tol <= 0.0) o.refine_tol = 1e-11;
+  if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
+  if (o.refine_tol <= 0.0) o.refine_tol = 1e-10;
   if (o.bound_tol <= 0.0) o.bound_tol = 1e-9;
   hipGetDevice(&h->device);
   h->n = n; h->nu = nu; h->n_aug = n_aug;
@@ -714,15 +789,15 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   int rc = 0;
 #define A_(ptr, cnt) if (!rc) rc = dev_alloc(h, &(ptr), (size_t)(cnt))
   A_(h->Pt, h->tiles * nb2); A_(h->P32, (size_t)np * np); A_(h->P64, (size_t)np * np);
-  A_(h->tq64, (size_t)np * ka); A_(h->Kunc32, (size_t)np * ka);
-  A_(h->L, (size_t)S * h->tiles * nb2); A_(h->Y, (size_t)S * h->T * nb2);
+  A_(h->tq64, (size_t)np * ka); A_(h->Kunc32, (size_t)np * ka); A_(h->pdiag, np);
+  A_(h->L, (size_t)S * h->tiles * nb2); A_(h->Y, (size_t)S * h->T * nb2); A_(h->Dacc, (size_t)S * h->T * nb2);
   QpDev& d = h->d;
   const size_t V = (size_t)S * np;
   A_(d.u, V); A_(d.zu, V); A_(d.zl, V); A_(d.lbv, V); A_(d.ubv, V); A_(d.q, V); A_(d.PU, V);
   A_(d.rd, V); A_(d.rhs, V); A_(d.sol, V); A_(d.dua, V); A_(d.dvec, V); A_(d.mask, V); A_(d.uunc, V);
-  A_(d.x, V); A_(d.q64, V); A_(d.PX, V); A_(d.st, V);
+  A_(d.x, V); A_(d.q64, V); A_(d.PX, V); A_(d.r64, V); A_(d.p64, V); A_(d.v64, V); A_(d.st, V);
   A_(d.phase, S); A_(d.f_factor, S); A_(d.f_solve1, S); A_(d.f_solve2, S); A_(d.ipm_it, S);
-  A_(d.nfac, S); A_(d.prounds, S); A_(d.rcnt, S); A_(d.rconv, S); A_(d.newset, S); A_(d.fail, S);
+  A_(d.nfac, S); A_(d.prounds, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.rz, S);
   A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
   A_(d.u_out, (size_t)S * n); A_(d.act_out, (size_t)S * h->words); A_(d.status_out, S); A_(d.iters_out, 2 * S);
   A_(h->x0_64, (size_t)S * ka); A_(h->x0_32, (size_t)S * ka);
@@ -735,14 +810,29 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   d.ipm_tol = o.ipm_tol; d.refine_tol = o.refine_tol; d.bound_tol = o.bound_tol; d.stat_tol = 1e-8;
 
   // host-side packing of the shared matrices (one-time setup)
-  std::vector<float> pt(h->tiles * nb2, 0.f), p32((size_t)np * np, 0.f), k32((size_t)np * ka, 0.f);
+  std::vector<float> pt(h->tiles * nb2, 0.f), p32((size_t)np * np, 0.f), k32((size_t)np * ka, 0.f), pdg(np, 1.f);
   std::vector<double> p64((size_t)np * np, 0.0), t64((size_t)np * ka, 0.0);
-  for (int r = 0; r < n; ++r)
+  {
+    std::vector<double> dg(n);
+    for (int r = 0; r < n; ++r) dg[r] = P[(size_t)r * n + r];
+    std::nth_element(dg.begin(), dg.begin() + n / 2, dg.end());
+    h->pscale = dg[n / 2];
+    if (!(h->pscale > 0.0)) { set_error("P has a non-positive diagonal"); nnmpc_qp_destroy(h); return NNMPC_EINVAL; }
+  }
+  const double ips = 1.0 / h->pscale;
+  float pdmax = 0.f;
+  for (int r = 0; r < n; ++r) {
+    pdg[r] = (float)(P[(size_t)r * n + r] * ips);
+    pdmax = std::max(pdmax, pdg[r]);
     for (int c = 0; c <= r; ++c) {
       const double v = P[(size_t)r * n + c];  // lower triangle is authoritative
       p64[(size_t)r * np + c] = v; p64[(size_t)c * np + r] = v;
-      p32[(size_t)r * np + c] = (float)v; p32[(size_t)c * np + r] = (float)v;
+      p32[(size_t)r * np + c] = (float)(v * ips); p32[(size_t)c * np + r] = (float)(v * ips);
     }
+  }
+  d.pscale = h->pscale;
+  d.delta = 16.f * 5.96e-8f * pdmax;   // keeps the f32 Cholesky positive for cond(P) >~ 1e7
+  d.pdiag = h->pdiag;
   for (int i = 0; i < h->T; ++i)
     for (int j = 0; j <= i; ++j) {
       float* t = pt.data() + ((size_t)i * (i + 1) / 2 + j) * nb2;
@@ -750,7 +840,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
         for (int c = 0; c < NB; ++c) {
           const int gr = i * NB + r, gc = j * NB + c;
           float v = 0.f;
-          if (gr < n && gc < n) v = (float)(gc <= gr ? P[(size_t)gr * n + gc] : P[(size_t)gc * n + gr]);
+          if (gr < n && gc < n) v = (float)((gc <= gr ? P[(size_t)gr * n + gc] : P[(size_t)gc * n + gr]) * ips);
           else if (gr == gc) v = 1.f;
           t[(size_t)r * NB + c] = v;
         }
@@ -766,6 +856,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (e == hipSuccess) e = hipMemcpy(h->P64, p64.data(), p64.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->tq64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->Kunc32, k32.data(), k32.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->pdiag, pdg.data(), pdg.size() * 4, hipMemcpyHostToDevice);
   if (e != hipSuccess) { set_error("upload of P/tq failed: %s", hipGetErrorString(e)); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   *out = h;
   return NNMPC_OK;
