@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: condensed-QP solves/sec of the CDU offline-datagen hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cdu|cstrs] [--batch B]
+
+One "step" = one pass of the hot path (q = tq x0 -> batched PDIP + polish ->
+first moves) over one batch of B synthetic CDU-size problems per GPU
+(Nx=252, Nu=32, N=140 -> n=4480 variables, m=8960 box rows; reference sizes
+cdu_parameters.py:99-102), inputs already resident in HBM.  N > 1: one process
+per GPU (torch.distributed, backend nccl = RCCL), the sample batch is sharded
+(weak scaling: B per GPU), no collective during the solves and ONE gather of
+the first moves over xGMI at the end of every step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3  # MI355X dense f32 matrix/vector peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s=30.0):
+    """Restated reference CPU path (oracle.qp.coneqp_l: cvxopt-style dense-G PDIP,
+    fp64, one problem at a time) timed on this host.  Bounded sample."""
+    from oracle import qp as oqp
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    n = P.shape[0]
+    done, t0, its = 0, time.time(), []
+    for b in range(x0.shape[0]):
+        G, h = oqp.box_as_Gh(nu, N, lb[b], ub[b])
+        info = {}
+        oqp.coneqp_l(P, tq @ x0[b], G, h, info=info)
+        its.append(info["iterations"])
+        done += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": done / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
+            "sample": f"{done} problem(s) of the same seeded batch, n={n}, m={2 * n}, dense G, "
+                      f"cvxopt-default tolerances, mean {np.mean(its):.1f} PDIP iterations, {dt:.1f} s",
+            "paper_reference": "35 s/solve mean on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cdu", choices=["cdu", "cstrs"])
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step")
+    ap.add_argument("--slots", type=int, default=0, help="resident problems per wave")
+    ap.add_argument("--sx", type=float, default=2.0, help="state spread of the synthetic samples")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from industrial_nnmpc_2021_amd import synthetic
+    from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+
+    B = args.batch or (1024 if args.workload == "cdu" else 16384)
+    slots = args.slots or (512 if args.workload == "cdu" else 8192)
+    pl = synthetic.plant(args.workload, seed=0)
+    P, tq, nu = build_regulator_matrices(pl)
+    n, n_aug, N = P.shape[0], tq.shape[1], pl["N"]
+    qp = BatchedBoxQP(P, tq, nu, max_batch=min(slots, B))
+
+    # every rank draws its own shard of the seeded sample stream
+    s = synthetic.samples(pl, B, seed=1000 + rank, sx=args.sx)
+    x0_h = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), axis=1)
+    lb_h, ub_h = pl["ulb"].T - s["us"], pl["uub"].T - s["us"]
+    x0 = torch.from_numpy(x0_h).to(dev)
+    lb = torch.from_numpy(np.ascontiguousarray(lb_h)).to(dev)
+    ub = torch.from_numpy(np.ascontiguousarray(ub_h)).to(dev)
+    us = torch.from_numpy(s["us"]).to(dev)
+    u = torch.empty((B, n), dtype=torch.float64, device=dev)
+    act = torch.empty((B, qp.words), dtype=torch.int32, device=dev)
+    status = torch.empty((B,), dtype=torch.int32, device=dev)
+    iters = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    gathered = [torch.empty((B, nu), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+
+    def step():
+        qp.solve_batch_device(B, x0, lb, ub, u, act, status, iters)
+        first = (u[:, :nu] + us).contiguous()      # get_control_sequence adds us back (:689); ut = useq[0:Nu] (:856)
+        if world > 1:
+            dist.gather(first, gathered, dst=0)     # the single RCCL gather over xGMI
+        return first
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    qp.set_profiling(True)
+    qp.stats(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = qp.stats()
+    status_h = status.cpu().numpy()
+    iters_h = iters.cpu().numpy()
+
+    if rank == 0:
+        out = {
+            "metric": "condensed-QP solves/sec (CDU offline datagen)" if args.workload == "cdu"
+                      else "condensed-QP solves/sec (CSTRs offline datagen)",
+            "value": world * B * args.steps / dt, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}_offline_data: synthetic {args.workload.upper()}-size plant "
+                                   f"(n={n} vars, m={2 * n} box rows, n_aug={n_aug}), {B} sampled x0 per GPU per step, "
+                                   f"waves of {min(slots, B)} resident problems",
+                       "batch_per_gpu": B, "sx": args.sx, "parallelism": f"dp{world} (sharded samples, 1 RCCL gather/step)"},
+            "solver": {"status_hist": np.bincount(status_h, minlength=3).tolist(),
+                       "mean_pdip_iters": float(iters_h[:, 0].mean()), "mean_factorizations": float(iters_h[:, 1].mean()),
+                       "max_factorizations": int(iters_h[:, 1].max()), "lockstep_rounds_per_step": st["rounds"] / args.steps},
+        }
+        # ---- roofline of the dominant kernel (chol_panel_k: MFMA f32), hipEvent-timed in the timed region
+        fl, ms = st["panel_flops"], st["panel_ms"]
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out["roofline"] = {"kernel": "chol_panel_k", "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                           "launches": st["panel_launches"], "avg_launch_ms": ms / max(1, st["panel_launches"]),
+                           "time_share": {"chol_panel": ms / st["total_ms"], "chol_diag": st["diag_ms"] / st["total_ms"],
+                                          "trsv": st["trsv_ms"] / st["total_ms"]},
+                           # whole-solve rate in the survey's dense-PDIP flop model: factorisations * n^3/3
+                           "cholesky_flops_over_solve_time_TFLOPs": st["factorizations"] * n ** 3 / 3 / (st["total_ms"] * 1e-3) / 1e12}
+        # ---- parity spot check against the fp64 oracle on the first problems of the batch
+        if not args.no_parity:
+            from oracle import qp as oqp
+            k = 2 if args.workload == "cdu" else 8
+            u_h = u[:k].cpu().numpy()
+            a_h = act[:k].cpu().numpy().view(np.uint32)
+            errs, ham = [], 0
+            Ps = np.tril(P) + np.tril(P, -1).T
+            for b in range(k):
+                info = {"nu": nu}
+                xe = oqp.solve_exact_box(Ps, tq @ x0_h[b], np.tile(lb_h[b], N), np.tile(ub_h[b], N), info=info)
+                rows = np.zeros(2 * n, bool)
+                rows[info["active"]] = True
+                bits = np.unpackbits(a_h[b].view(np.uint8), bitorder="little")[:2 * n].astype(bool)
+                errs.append(float(np.abs(u_h[b] - xe).max() / max(1.0, np.abs(xe).max())))
+                ham += int((bits != rows).sum())
+            out["parity"] = {"checked": k, "max_rel_err_vs_fp64_oracle": max(errs), "active_set_hamming": ham}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, x0_h, lb_h, ub_h,
+                                               budget_s=20.0 if args.workload == "cdu" else 10.0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -189,3 +189,89 @@ def box_as_Gh(n_stage, N, lb, ub):
     G = sla.block_diag(*([E] * N))
     h = np.tile(np.concatenate((np.ravel(ub), -np.ravel(lb))), N)
     return G, h
+
+
+def solve_exact_box(P, q, lb, ub, tol=1e-11, maxiters=80, info=None):
+    """Exact optimum of  min 1/2 x'Px + q'x,  lb <= x <= ub  (per-variable bounds).
+
+    Same problem as ``solve_exact(P, q, *box_as_Gh(...))`` but exploits G = [I; -I]
+    (the KKT matrix is P + diag(d)), so it is usable at the CDU size (n = 4480).
+    ``info['active']`` lists active rows in the reference's G row order when
+    ``info['nu']`` is given (rows k*2nu + c upper, k*2nu + nu + c lower).
+    """
+    P = _sym_lower(np.asarray(P, float))
+    q = np.asarray(q, float).reshape(-1)
+    lb = np.asarray(lb, float).reshape(-1)
+    ub = np.asarray(ub, float).reshape(-1)
+    n = q.size
+    FP = sla.cho_factor(P, lower=True)
+    x = np.clip(sla.cho_solve(FP, -q), lb + 0.05 * (ub - lb), ub - 0.05 * (ub - lb))
+    g = P @ x + q
+    mu0 = 0.1 * np.mean(np.abs(g)) + 1e-3
+    su, sl = ub - x, x - lb
+    zu, zl = np.maximum(-g, 0) + mu0 / su, np.maximum(g, 0) + mu0 / sl
+    scale = max(1.0, np.abs(q).max())
+    for _ in range(maxiters):
+        su, sl = ub - x, x - lb
+        g = P @ x + q
+        rd = g + zu - zl
+        gap = float(su @ zu + sl @ zl)
+        mu = gap / (2 * n)
+        if np.abs(rd).max() <= tol * scale and mu <= tol * scale:
+            break
+        F = sla.cho_factor(P + np.diag(zu / su + zl / sl), lower=True)
+        smu, dua = 0.0, None
+        for i in (0, 1):
+            if i == 0:
+                rhs = -g
+            else:
+                rhs = -rd + zu - smu / su - dua * dzu / su - zl + smu / sl - dua * dzl / sl
+            du = sla.cho_solve(F, rhs)
+            if i == 0:
+                dzu, dzl = -zu + zu * du / su, -zl - zl * du / sl
+                dua = du
+                nzu, nzl = dzu, dzl
+            else:
+                rcu = -su * zu + smu + dua * dzu
+                rcl = -sl * zl + smu - dua * dzl
+                nzu, nzl = (rcu + zu * du) / su, (rcl - zl * du) / sl
+            t = max(0.0, np.max(du / su), np.max(-du / sl), np.max(-nzu / zu), np.max(-nzl / zl))
+            if i == 0:
+                a = 1.0 if t == 0 else min(1.0, 1.0 / t)
+                ga = float((su - a * du) @ (zu + a * dzu) + (sl + a * du) @ (zl + a * dzl))
+                smu = min(1.0, max(0.0, ga / gap)) ** 3 * mu
+            else:
+                a = 1.0 if t == 0 else min(1.0, 0.995 / t)
+        x, zu, zl = x + a * du, np.maximum(zu + a * nzu, 1e-300), np.maximum(zl + a * nzl, 1e-300)
+    # active-set polish (primal-dual active-set steps on the exact free-block solve)
+    au, al = zu > su, zl > sl
+    both = au & al
+    au, al = au & ~(both & (zl * su > zu * sl)), al & ~(both & (zl * su <= zu * sl))
+    for _ in range(100):
+        act = au | al
+        xb = np.where(au, ub, np.where(al, lb, 0.0))
+        fr = ~act
+        xn = xb.copy()
+        if fr.any():
+            rhs = -(q[fr] + P[np.ix_(fr, act)] @ xb[act])
+            xn[fr] = sla.cho_solve(sla.cho_factor(P[np.ix_(fr, fr)], lower=True), rhs)
+        g = P @ xn + q
+        vu, vl = fr & (xn > ub + 1e-12 * (1 + np.abs(ub))), fr & (xn < lb - 1e-12 * (1 + np.abs(lb)))
+        du_, dl_ = au & (g >= 0), al & (g <= 0)
+        x = xn
+        if not (vu.any() or vl.any() or du_.any() or dl_.any()):
+            break
+        au, al = (au & ~du_) | vu, (al & ~dl_) | vl
+    if info is not None:
+        g = P @ x + q
+        lam_u, lam_l = np.where(au, -g, 0.0), np.where(al, g, 0.0)
+        info.update(au=au, al=al, kkt=(np.abs(g + lam_u - lam_l).max(), max(np.max(x - ub), np.max(lb - x), 0.0),
+                                      max(np.max(-lam_u), np.max(-lam_l), 0.0)))
+        nu = info.get("nu")
+        if nu:
+            k, c = np.arange(n) // nu, np.arange(n) % nu
+            rows = np.zeros(2 * n, bool)
+            rows[k * 2 * nu + c] = au
+            rows[k * 2 * nu + nu + c] = al
+            info["active"] = np.flatnonzero(rows)
+    return x
