@@ -86,8 +86,8 @@ def main():
     from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
     from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
 
-    B = args.batch or (1024 if args.workload == "cdu" else 16384)
-    slots = args.slots or (512 if args.workload == "cdu" else 8192)
+    B = args.batch or (4096 if args.workload == "cdu" else 32768)
+    slots = args.slots or (1024 if args.workload == "cdu" else 8192)
     pl = synthetic.plant(args.workload, seed=0)
     P, tq, nu = build_regulator_matrices(pl)
     n, n_aug, N = P.shape[0], tq.shape[1], pl["N"]

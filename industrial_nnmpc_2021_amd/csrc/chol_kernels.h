@@ -235,38 +235,11 @@ __global__ __launch_bounds__(256) void chol_diag_k(CholArgs a, int j) {
   }
 }
 
-// One K-chunk (32 columns MC*32.. of C) of  out += C * Y';  C lives in the
-// accumulators of the waves with wc == (MC*32)/WT, sub-tile column MJ (static).
+// Stage columns [32 MC, 32 MC + 32) of an NB x NB matrix held in accumulators
+// (wave (wr, wc) owns rows wr*WT.., cols wc*WT..) into an LDS chunk image.
 template <int NB, int MC>
-__device__ __forceinline__ void second_gemm_chunk(
-    const f32x16 (&acc)[TileCfg<NB>::MT][TileCfg<NB>::MT],
-    f32x16 (&out)[TileCfg<NB>::MT][TileCfg<NB>::MT], const float* Yj, float* sA, float* sB,
-    int wr, int wc, int lane, int tid) {
-  using C = TileCfg<NB>;
-  constexpr int WT = C::WT;
-  constexpr int NEED_WC = (MC * 32) / WT;
-  constexpr int MJ = ((MC * 32) % WT) / 32;
-  if (wc == NEED_WC) {
-#pragma unroll
-    for (int mi = 0; mi < C::MT; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sA[(wr * WT + mi * 32 + acc_row(r, lane)) * LDS_LD + acc_col(lane)] = acc[mi][MJ][r];
-  }
-  f32x4 rb[C::LD4];
-  load_chunk<NB>(rb, Yj + MC * 32, NB, tid);
-  store_chunk<NB>(rb, sB, tid);
-  __syncthreads();
-  mma_chunk<NB>(out, sA, sB, wr, wc, lane);
-  __syncthreads();
-}
-
-// One K-chunk of  S += X X'  with X (NB x NB) held in accumulators: columns
-// MC*32.. of X are staged once and used as both MFMA operands.
-template <int NB, int MC>
-__device__ __forceinline__ void syrk_chunk(const f32x16 (&x)[TileCfg<NB>::MT][TileCfg<NB>::MT],
-                                           f32x16 (&s)[TileCfg<NB>::MT][TileCfg<NB>::MT], float* sA,
-                                           int wr, int wc, int lane) {
+__device__ __forceinline__ void stage_acc_chunk(const f32x16 (&x)[TileCfg<NB>::MT][TileCfg<NB>::MT],
+                                                float* sA, int wr, int wc, int lane) {
   using C = TileCfg<NB>;
   constexpr int WT = C::WT;
   constexpr int NEED_WC = (MC * 32) / WT;
@@ -278,29 +251,27 @@ __device__ __forceinline__ void syrk_chunk(const f32x16 (&x)[TileCfg<NB>::MT][Ti
       for (int r = 0; r < 16; ++r)
         sA[(wr * WT + mi * 32 + acc_row(r, lane)) * LDS_LD + acc_col(lane)] = x[mi][MJ][r];
   }
-  __syncthreads();
-  mma_chunk<NB>(s, sA, sA, wr, wc, lane);
-  __syncthreads();
 }
 
+// Panel tile (i, j), i > j, of step j:
+//   acc  = sum_k L[i,k] L[j,k]' - mask o P[i,j]                 (= -C; P preloaded into acc)
+//   nout = acc Y_j'  (= -L[i,j]; Y_j lower triangular: zero 32-blocks skipped)
+//   Dacc[i] += nout nout'  (lower 32-blocks only), accumulated on top of the tile loaded from HBM.
+// The two epilogue products run chunk by chunk through alternating LDS buffers
+// (one barrier per chunk), the next Y chunk is fetched while the current one is multiplied.
 template <int NB>
-__global__ __launch_bounds__(256) void chol_panel_k(CholArgs a, int j) {
+__global__ __launch_bounds__(256, 2) void chol_panel_k(CholArgs a, int j) {
   const int p = blockIdx.y;
   if (!a.flag[p]) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using C = TileCfg<NB>;
+  constexpr int NC = NB / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int i = j + 1 + blockIdx.x;
   float* Lp = a.L + (size_t)p * a.tiles * NB * NB;
 
   f32x16 acc[C::MT][C::MT];
-  zero_acc<NB>(acc);
-  TileRowOp<NB> A{Lp + tile_off(i, 0, NB * NB)};
-  TileRowOp<NB> B{Lp + tile_off(j, 0, NB * NB)};
-  tile_gemm_nt<NB>(acc, A, B, j * NB, lds, false);
-
-  // C = mask_i mask_j' o P[i,j] - acc   (kept in registers)
   const float* Pij = a.Pt + tile_off(i, j, NB * NB);
   const float* mki = a.mask + (size_t)p * a.np + i * NB;
   const float* mkj = a.mask + (size_t)p * a.np + j * NB;
@@ -312,21 +283,38 @@ __global__ __launch_bounds__(256) void chol_panel_k(CholArgs a, int j) {
       for (int r = 0; r < 16; ++r) {
         const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
         const int col = wc * C::WT + mj * 32 + acc_col(lane);
-        acc[mi][mj][r] = mki[row] * mkj[col] * Pij[row * NB + col] - acc[mi][mj][r];
+        acc[mi][mj][r] = -(mki[row] * mkj[col] * Pij[row * NB + col]);
       }
+  TileRowOp<NB> A{Lp + tile_off(i, 0, NB * NB)};
+  TileRowOp<NB> B{Lp + tile_off(j, 0, NB * NB)};
+  tile_gemm_nt<NB>(acc, A, B, j * NB, lds, false);
 
-  // out = C * Y_j'  : K-chunks of C go registers -> LDS, chunks of Y global -> LDS
+  // ---- nout = acc * Y_j'
   f32x16 out[C::MT][C::MT];
   zero_acc<NB>(out);
   const float* Yj = a.Y + ((size_t)p * a.T + j) * NB * NB;
-  float* sA = lds;
-  float* sB = lds + C::STAGE_FLOATS;
-  second_gemm_chunk<NB, 0>(acc, out, Yj, sA, sB, wr, wc, lane, tid);
-  second_gemm_chunk<NB, 1>(acc, out, Yj, sA, sB, wr, wc, lane, tid);
-  if constexpr (NB == 128) {
-    second_gemm_chunk<NB, 2>(acc, out, Yj, sA, sB, wr, wc, lane, tid);
-    second_gemm_chunk<NB, 3>(acc, out, Yj, sA, sB, wr, wc, lane, tid);
+  f32x4 rb[C::LD4];
+  load_chunk<NB>(rb, Yj, NB, tid);
+  auto tri = [&](int mc) {  // chunk mc of Y' only feeds output 32-blocks cb >= mc
+    return [=](int, int mj) { return mc <= wc * C::MT + mj; };
+  };
+#define NNMPC_TRSM_CHUNK(MC)                                                        \
+  {                                                                                 \
+    float* sA = lds + ((MC) & 1) * 2 * C::STAGE_FLOATS;                             \
+    float* sB = sA + C::STAGE_FLOATS;                                               \
+    stage_acc_chunk<NB, MC>(acc, sA, wr, wc, lane);                                 \
+    store_chunk<NB>(rb, sB, tid);                                                   \
+    __syncthreads();                                                                \
+    if ((MC) + 1 < NC) load_chunk<NB>(rb, Yj + ((MC) + 1) * 32, NB, tid);           \
+    mma_chunk_pred<NB>(out, sA, sB, wr, wc, lane, tri(MC));                         \
   }
+  NNMPC_TRSM_CHUNK(0)
+  NNMPC_TRSM_CHUNK(1)
+  if constexpr (NB == 128) {
+    NNMPC_TRSM_CHUNK(2)
+    NNMPC_TRSM_CHUNK(3)
+  }
+#undef NNMPC_TRSM_CHUNK
 
   float* Lij = Lp + tile_off(i, j, NB * NB);
 #pragma unroll
@@ -337,27 +325,49 @@ __global__ __launch_bounds__(256) void chol_panel_k(CholArgs a, int j) {
       for (int r = 0; r < 16; ++r) {
         const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
         const int col = wc * C::WT + mj * 32 + acc_col(lane);
-        Lij[row * NB + col] = out[mi][mj][r];
+        Lij[row * NB + col] = -out[mi][mj][r];
       }
 
-  // Dacc[i] += L[i,j] L[i,j]'   (the diagonal tile's update, done while the tile is on chip)
-  zero_acc<NB>(acc);
-  syrk_chunk<NB, 0>(out, acc, sA, wr, wc, lane);
-  syrk_chunk<NB, 1>(out, acc, sA, wr, wc, lane);
-  if constexpr (NB == 128) {
-    syrk_chunk<NB, 2>(out, acc, sA, wr, wc, lane);
-    syrk_chunk<NB, 3>(out, acc, sA, wr, wc, lane);
-  }
+  // ---- Dacc[i] += nout nout'   (32-blocks with column block <= row block)
   float* Di = a.Dacc + ((size_t)p * a.T + i) * NB * NB;
+  auto low = [=](int mi, int mj) { return wc * C::MT + mj <= wr * C::MT + mi; };
 #pragma unroll
   for (int mi = 0; mi < C::MT; ++mi)
 #pragma unroll
     for (int mj = 0; mj < C::MT; ++mj)
+      if (low(mi, mj)) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
-        const int col = wc * C::WT + mj * 32 + acc_col(lane);
-        Di[row * NB + col] += acc[mi][mj][r];
+        for (int r = 0; r < 16; ++r) {
+          const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
+          const int col = wc * C::WT + mj * 32 + acc_col(lane);
+          acc[mi][mj][r] = Di[row * NB + col];
+        }
+      }
+#define NNMPC_SYRK_CHUNK(MC)                                                        \
+  {                                                                                 \
+    float* sA = lds + (((MC) + NC) & 1) * 2 * C::STAGE_FLOATS;                      \
+    stage_acc_chunk<NB, MC>(out, sA, wr, wc, lane);                                 \
+    __syncthreads();                                                                \
+    mma_chunk_pred<NB>(acc, sA, sA, wr, wc, lane, low);                             \
+  }
+  NNMPC_SYRK_CHUNK(0)
+  NNMPC_SYRK_CHUNK(1)
+  if constexpr (NB == 128) {
+    NNMPC_SYRK_CHUNK(2)
+    NNMPC_SYRK_CHUNK(3)
+  }
+#undef NNMPC_SYRK_CHUNK
+#pragma unroll
+  for (int mi = 0; mi < C::MT; ++mi)
+#pragma unroll
+    for (int mj = 0; mj < C::MT; ++mj)
+      if (low(mi, mj)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wr * C::WT + mi * 32 + acc_row(r, lane);
+          const int col = wc * C::WT + mj * 32 + acc_col(lane);
+          Di[row * NB + col] = acc[mi][mj][r];
+        }
       }
 }
 

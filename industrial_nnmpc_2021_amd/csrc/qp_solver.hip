@@ -47,7 +47,12 @@ struct QpDev {
   // f64 [slots][np]
   double *x, *q64, *PX, *r64, *p64, *v64;   // PX = P64 * v64
   unsigned char* st;  // [slots][np]  0 free, 1 at upper, 2 at lower
-  const double *lb64, *ub64;  // [slots][nu]
+  double *lb64, *ub64;        // [slots][nu] bounds of the problem resident in the slot
+  // segment-level inputs (problem-indexed) the slots are (re)filled from
+  const double *q64_all, *lb_all, *ub_all;   // [seg][np], [seg][nu], [seg][nu]
+  const float* uunc_all;                      // [seg][np]
+  int *slot_prob, *age, *next_prob;
+  int seg_count, max_rounds;
   int *phase, *f_factor, *f_solve1, *f_solve2, *ipm_it, *nfac, *prounds, *rcnt, *psub, *fail;
   float *mu, *gap, *smu, *qscale;
   double* rz;
@@ -111,37 +116,50 @@ __device__ int block_sum_i(int v, int* sh) {
 #define SLACK_MIN 1e-12f
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void init_k(QpDev d, int nprob) {
+// Continuous batching: every free (DONE) slot grabs the next unsolved problem of
+// the segment and is initialised for the PDIP (warm start = clipped u_unc).
+__global__ __launch_bounds__(256) void refill_k(QpDev d) {
   __shared__ float shf[4];
+  __shared__ int s_idx;
   const int p = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)p * d.np;
-  if (p >= nprob) {  // unused slot of this wave
-    if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
-    for (int r = tid; r < d.np; r += 256) { d.u[o + r] = 0.f; d.x[o + r] = 0.0; d.v64[o + r] = 0.0; }
+  if (d.phase[p] != PH_DONE) return;
+  if (tid == 0) s_idx = atomicAdd(d.next_prob, 1);
+  __syncthreads();
+  const int idx = s_idx;
+  if (idx >= d.seg_count) {
+    if (tid == 0) d.slot_prob[p] = -1;
     return;
+  }
+  const size_t oi = (size_t)idx * d.np;
+  if (tid < d.nu) {
+    d.lb64[(size_t)p * d.nu + tid] = d.lb_all[(size_t)idx * d.nu + tid];
+    d.ub64[(size_t)p * d.nu + tid] = d.ub_all[(size_t)idx * d.nu + tid];
   }
   float qm = 0.f;
   for (int r = tid; r < d.np; r += 256) {
     if (r < d.n) {
       const int c = r % d.nu;
-      const float lb = (float)d.lb64[(size_t)p * d.nu + c], ub = (float)d.ub64[(size_t)p * d.nu + c];
-      const float q = (float)(d.q64[o + r] / d.pscale);
+      const float lb = (float)d.lb_all[(size_t)idx * d.nu + c], ub = (float)d.ub_all[(size_t)idx * d.nu + c];
+      const double q64 = d.q64_all[oi + r];
+      const float q = (float)(q64 / d.pscale);
       const float w = ub - lb;
-      float u0 = d.uunc[o + r];
+      float u0 = d.uunc_all[oi + r];
       u0 = fminf(fmaxf(u0, lb + 0.05f * w), ub - 0.05f * w);
-      d.lbv[o + r] = lb; d.ubv[o + r] = ub; d.q[o + r] = q; d.u[o + r] = u0;
-      d.zu[o + r] = 0.f; d.zl[o + r] = 0.f;
+      d.lbv[o + r] = lb; d.ubv[o + r] = ub; d.q[o + r] = q; d.u[o + r] = u0; d.q64[o + r] = q64;
       qm = fmaxf(qm, fabsf(q));
     } else {
-      d.lbv[o + r] = -1.f; d.ubv[o + r] = 1.f; d.q[o + r] = 0.f; d.u[o + r] = 0.f;
-      d.zu[o + r] = 0.f; d.zl[o + r] = 0.f; d.q64[o + r] = 0.0;
+      d.lbv[o + r] = -1.f; d.ubv[o + r] = 1.f; d.q[o + r] = 0.f; d.u[o + r] = 0.f; d.q64[o + r] = 0.0;
     }
+    d.zu[o + r] = 0.f; d.zl[o + r] = 0.f;
     d.mask[o + r] = 1.f; d.dvec[o + r] = 0.f; d.rhs[o + r] = 0.f; d.sol[o + r] = 0.f;
     d.dua[o + r] = 0.f; d.rd[o + r] = 0.f; d.x[o + r] = 0.0; d.st[o + r] = 0;
     d.r64[o + r] = 0.0; d.p64[o + r] = 0.0; d.v64[o + r] = 0.0;
   }
   qm = block_max(qm, shf);
   if (tid == 0) {
+    d.slot_prob[p] = idx;
+    d.age[p] = 0;
     d.qscale[p] = fmaxf(1.f, qm);
     d.phase[p] = PH_INIT;
     d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
@@ -149,11 +167,21 @@ __global__ __launch_bounds__(256) void init_k(QpDev d, int nprob) {
     d.mu[p] = d.gap[p] = d.smu[p] = 0.f; d.rz[p] = 0.0;
   }
 }
+// Start of a segment: every slot is free.
+__global__ void reset_slots_k(QpDev d) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < d.slots) {
+    d.phase[p] = PH_DONE; d.slot_prob[p] = -1; d.age[p] = 0;
+    d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
+  }
+  if (p == 0) *d.next_prob = 0;
+}
 
 __device__ void write_outputs(const QpDev& d, int p, int status) {
   const int tid = threadIdx.x;
   const size_t o = (size_t)p * d.np;
-  for (int r = tid; r < d.n; r += 256) d.u_out[(size_t)p * d.n + r] = d.x[o + r];
+  const size_t pi = (size_t)d.slot_prob[p];
+  for (int r = tid; r < d.n; r += 256) d.u_out[pi * d.n + r] = d.x[o + r];
   const int m = 2 * d.n;
   for (int w = tid; w < d.words; w += 256) {
     uint32_t bits = 0;
@@ -165,12 +193,11 @@ __device__ void write_outputs(const QpDev& d, int p, int status) {
         bits |= (uint32_t)hit << b;
       }
     }
-    d.act_out[(size_t)p * d.words + w] = bits;
+    if (d.act_out) d.act_out[pi * d.words + w] = bits;
   }
   if (tid == 0) {
-    d.status_out[p] = d.fail[p] ? NNMPC_ST_NUMERIC : status;
-    d.iters_out[2 * p] = d.ipm_it[p];
-    d.iters_out[2 * p + 1] = d.nfac[p];
+    if (d.status_out) d.status_out[pi] = d.fail[p] ? NNMPC_ST_NUMERIC : status;
+    if (d.iters_out) { d.iters_out[2 * pi] = d.ipm_it[p]; d.iters_out[2 * pi + 1] = d.nfac[p]; }
   }
 }
 
@@ -250,6 +277,20 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
   int ph = d.phase[p];
   if (ph == PH_DONE) return;
   const int n = d.n;
+  {
+    const int age = d.age[p] + 1;   // rounds this problem has been resident
+    __syncthreads();
+    if (tid == 0) d.age[p] = age;
+    if (age > d.max_rounds) {       // budget exhausted: emit the current iterate, uncertified
+      if (ph != PH_POLISH) {
+        for (int r = tid; r < n; r += 256) { d.x[o + r] = (double)d.u[o + r]; d.st[o + r] = 0; }
+        __syncthreads();
+      }
+      write_outputs(d, p, NNMPC_ST_MAXITER);
+      if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
+      return;
+    }
+  }
 
   if (ph == PH_INIT) {
     float s = 0.f;
@@ -495,20 +536,6 @@ __global__ __launch_bounds__(256) void stage_post_k(QpDev d) {
   }
 }
 
-// Budget exhausted: emit whatever we have, uncertified.
-__global__ __launch_bounds__(256) void force_finish_k(QpDev d) {
-  const int p = blockIdx.x, tid = threadIdx.x;
-  const size_t o = (size_t)p * d.np;
-  const int ph = d.phase[p];
-  if (ph == PH_DONE) return;
-  if (ph != PH_POLISH) {
-    for (int r = tid; r < d.n; r += 256) { d.x[o + r] = (double)d.u[o + r]; d.st[o + r] = 0; }
-    __syncthreads();
-  }
-  write_outputs(d, p, NNMPC_ST_MAXITER);
-  if (tid == 0) d.phase[p] = PH_DONE;
-}
-
 __global__ void f64_to_f32_k(float* dst, const double* src, size_t count) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -549,10 +576,13 @@ struct nnmpc_qp {
   float* Y;
   float* Dacc;
   QpDev d;
-  double *x0_64;  // [slots][ka]
+  int seg_max;          // problems per segment (q / warm start precomputed per segment)
+  double* x0_64;        // [seg_max][ka]
   float* x0_32;
-  double *lb_d, *ub_d;  // [slots][nu]
-  double* in_stage;     // device staging for host inputs
+  double* q64_all;      // [seg_max][np]
+  float* uunc_all;      // [seg_max][np]
+  double *lb_d, *ub_d;  // [seg_max][nu] staging for host inputs
+  double* in_stage;     // [seg_max][n_aug]
   hipStream_t stream;
   bool profiling;
   std::vector<hipEvent_t> ev_pool;
@@ -682,31 +712,41 @@ void solve_dispatch(nnmpc_qp* h, int nslots, const int* flag) {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e_)); return NNMPC_EHIP; } } while (0)
 
-int solve_wave(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_dev, const double* ub_dev,
-               double* u_dev, uint32_t* act_dev, int32_t* st_dev, int32_t* it_dev) {
+// One segment (<= h->seg_max problems): q and the warm start for the whole
+// segment by two GEMMs, then lock-step rounds over the resident slots with
+// finished slots refilled from the segment until it is exhausted.
+int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_dev, const double* ub_dev,
+                  double* u_dev, uint32_t* act_dev, int32_t* st_dev, int32_t* it_dev) {
   QpDev& d = h->d;
   hipStream_t s = h->stream;
-  const int slots = h->slots;
-  const int rows = ((nprob + 127) / 128) * 128;  // rows touched by GEMMs / per-slot kernels
-  d.lb64 = lb_dev; d.ub64 = ub_dev;
-  // q = tq x0 (f64), warm start u_unc = Kunc x0 (f32)
-  hipLaunchKernelGGL(pad_x0_k, dim3(256), dim3(256), 0, s, h->x0_64, h->x0_32, x0_dev, nprob, h->n_aug, h->ka, rows);
-  gemm64(h, d.q64, h->np, h->x0_64, h->ka, h->tq64, h->ka, rows, h->np, h->ka);
-  if (h->have_kunc) gemm32(h, d.uunc, h->np, h->x0_32, h->ka, h->Kunc32, h->ka, rows, h->np, h->ka);
-  else HIPCHK(hipMemsetAsync(d.uunc, 0, (size_t)rows * h->np * sizeof(float), s));
-  hipLaunchKernelGGL(init_k, dim3(rows), dim3(256), 0, s, d, nprob);
+  const int rows = h->slots;
+  const int segp = ((nprob + 127) / 128) * 128;
+  hipLaunchKernelGGL(pad_x0_k, dim3(512), dim3(256), 0, s, h->x0_64, h->x0_32, x0_dev, nprob, h->n_aug, h->ka, segp);
+  gemm64(h, h->q64_all, h->np, h->x0_64, h->ka, h->tq64, h->ka, segp, h->np, h->ka);
+  if (h->have_kunc) gemm32(h, h->uunc_all, h->np, h->x0_32, h->ka, h->Kunc32, h->ka, segp, h->np, h->ka);
+  else HIPCHK(hipMemsetAsync(h->uunc_all, 0, (size_t)segp * h->np * sizeof(float), s));
+  d.q64_all = h->q64_all; d.uunc_all = h->uunc_all; d.lb_all = lb_dev; d.ub_all = ub_dev;
+  d.seg_count = nprob;
+  d.u_out = u_dev; d.act_out = act_dev; d.status_out = st_dev; d.iters_out = it_dev;
+  hipLaunchKernelGGL(reset_slots_k, dim3((rows + 255) / 256), dim3(256), 0, s, d);
 
   int cnt[8];
   bool any_ipm = true, any_polish = false;
-  int round = 0;
-  for (; round < h->opts.max_rounds; ++round) {
+  int issued = 0;  // problems handed to slots so far (host mirror of *next_prob, upper bound)
+  const int hard_cap = 1000000;
+  for (int round = 0; round < hard_cap; ++round) {
     HIPCHK(hipMemsetAsync(d.counters, 0, 8 * sizeof(int), s));
+    if (issued < nprob) {
+      hipLaunchKernelGGL(refill_k, dim3(rows), dim3(256), 0, s, d);
+      any_ipm = true;
+    }
     if (any_ipm) gemm32(h, d.PU, h->np, d.u, h->np, h->P32, h->np, rows, h->np, h->np);
     if (any_polish) gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np);
     hipLaunchKernelGGL(stage_pre_k, dim3(rows), dim3(256), 0, s, d);
     HIPCHK(hipMemcpyAsync(cnt, d.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&issued, d.next_prob, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (cnt[CNT_ACTIVE] == 0) break;
+    if (cnt[CNT_ACTIVE] == 0 && issued >= nprob) break;
     any_ipm = cnt[CNT_IPM] > 0;
     any_polish = cnt[CNT_POLISH] > 0;
     h->stats.rounds += 1;
@@ -724,16 +764,9 @@ int solve_wave(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_de
       hipLaunchKernelGGL(stage_post_k, dim3(rows), dim3(256), 0, s, d);
     }
   }
-  if (round == h->opts.max_rounds) hipLaunchKernelGGL(force_finish_k, dim3(rows), dim3(256), 0, s, d);
-  // outputs
-  HIPCHK(hipMemcpyAsync(u_dev, d.u_out, (size_t)nprob * h->n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  if (act_dev) HIPCHK(hipMemcpyAsync(act_dev, d.act_out, (size_t)nprob * h->words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-  if (st_dev) HIPCHK(hipMemcpyAsync(st_dev, d.status_out, (size_t)nprob * sizeof(int), hipMemcpyDeviceToDevice, s));
-  if (it_dev) HIPCHK(hipMemcpyAsync(it_dev, d.iters_out, (size_t)nprob * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   h->stats.problems += nprob;
-  (void)slots;
   return 0;
 }
 
@@ -743,7 +776,7 @@ extern "C" {
 
 int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const double* P,
                     const double* tq, const double* Kunc, const nnmpc_qp_opts* opts) {
-  if (!out || !P || !tq || n <= 0 || nu <= 0 || n_aug <= 0 || n % nu != 0) {
+  if (!out || !P || !tq || n <= 0 || nu <= 0 || nu > 256 || n_aug <= 0 || n % nu != 0) {
     set_error("nnmpc_qp_create: bad arguments (n=%d nu=%d n_aug=%d)", n, nu, n_aug);
     return NNMPC_EINVAL;
   }
@@ -799,14 +832,25 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.phase, S); A_(d.f_factor, S); A_(d.f_solve1, S); A_(d.f_solve2, S); A_(d.ipm_it, S);
   A_(d.nfac, S); A_(d.prounds, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.rz, S);
   A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
-  A_(d.u_out, (size_t)S * n); A_(d.act_out, (size_t)S * h->words); A_(d.status_out, S); A_(d.iters_out, 2 * S);
-  A_(h->x0_64, (size_t)S * ka); A_(h->x0_32, (size_t)S * ka);
-  A_(h->lb_d, (size_t)S * nu); A_(h->ub_d, (size_t)S * nu);
-  A_(h->in_stage, (size_t)S * n_aug);
+  {
+    // segment size: as many problems as ~1.5 GB of (q f64 + warm start f32) rows allow
+    long long cap = (long long)(1.5e9 / (12.0 * np));
+    cap = std::max<long long>(cap, S);
+    cap = std::min<long long>(cap, 1 << 20);
+    h->seg_max = (int)((cap / 128) * 128);
+  }
+  const size_t G = h->seg_max;
+  A_(h->x0_64, G * ka); A_(h->x0_32, G * ka);
+  A_(h->q64_all, G * np); A_(h->uunc_all, G * np);
+  A_(h->lb_d, G * nu); A_(h->ub_d, G * nu);
+  A_(h->in_stage, G * n_aug);
+  A_(d.lb64, (size_t)S * nu); A_(d.ub64, (size_t)S * nu);
+  A_(d.slot_prob, S); A_(d.age, S); A_(d.next_prob, 1);
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
   d.n = n; d.np = np; d.nu = nu; d.slots = S; d.words = h->words;
   d.max_ipm = o.max_ipm_iters; d.max_polish = o.max_polish_rounds; d.max_refine = o.max_refine;
+  d.max_rounds = o.max_rounds;
   d.ipm_tol = o.ipm_tol; d.refine_tol = o.refine_tol; d.bound_tol = o.bound_tol; d.stat_tol = 1e-8;
 
   // host-side packing of the shared matrices (one-time setup)
@@ -890,20 +934,21 @@ int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double*
   if (!h || B < 0 || !x0 || !lb || !ub || !u) { set_error("nnmpc_qp_solve_batch: bad arguments"); return NNMPC_EINVAL; }
   if (B == 0) return NNMPC_OK;
   HIPCHK(hipSetDevice(h->device));
-  const int S = h->slots;
+  const int G = h->seg_max;
   size_t e_tot0 = 0;
   if (h->profiling) { e_tot0 = ev_get(h); hipEventRecord(h->ev_pool[e_tot0], h->stream); }
   // device scratch for outputs when the caller hands host pointers
   double* u_stage = nullptr; uint32_t* a_stage = nullptr; int32_t* s_stage = nullptr; int32_t* i_stage = nullptr;
+  const int gmax = std::min(G, (int)B);
   if (ptr_kind == NNMPC_HOST) {
-    HIPCHK(hipMalloc((void**)&u_stage, (size_t)S * h->n * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&a_stage, (size_t)S * h->words * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void**)&s_stage, (size_t)S * sizeof(int32_t)));
-    HIPCHK(hipMalloc((void**)&i_stage, (size_t)S * 2 * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void**)&u_stage, (size_t)gmax * h->n * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&a_stage, (size_t)gmax * h->words * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&s_stage, (size_t)gmax * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void**)&i_stage, (size_t)gmax * 2 * sizeof(int32_t)));
   }
   int rc = 0;
-  for (int b0 = 0; b0 < B && !rc; b0 += S) {
-    const int nb = std::min(S, B - b0);
+  for (int b0 = 0; b0 < B && !rc; b0 += G) {
+    const int nb = std::min(G, B - b0);
     const double *x0d, *lbd, *ubd;
     double* ud; uint32_t* ad; int32_t* sd; int32_t* idv;
     if (ptr_kind == NNMPC_HOST) {
@@ -919,7 +964,7 @@ int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double*
       sd = status ? status + b0 : nullptr;
       idv = iters ? iters + 2 * (size_t)b0 : nullptr;
     }
-    rc = solve_wave(h, nb, x0d, lbd, ubd, ud, ad, sd, idv);
+    rc = solve_segment(h, nb, x0d, lbd, ubd, ud, ad, sd, idv);
     if (!rc && ptr_kind == NNMPC_HOST) {
       HIPCHK(hipMemcpy(u + (size_t)b0 * h->n, u_stage, (size_t)nb * h->n * 8, hipMemcpyDeviceToHost));
       if (active) HIPCHK(hipMemcpy(active + (size_t)b0 * h->words, a_stage, (size_t)nb * h->words * 4, hipMemcpyDeviceToHost));
@@ -946,7 +991,7 @@ int nnmpc_qp_debug_factor_solve(nnmpc_qp* h, int32_t B, const float* dvec, const
   if (!h || B <= 0 || B > h->slots || !dvec || !mask || !rhs || !sol) { set_error("debug_factor_solve: bad arguments"); return NNMPC_EINVAL; }
   HIPCHK(hipSetDevice(h->device));
   QpDev& d = h->d;
-  const int rows = ((B + 127) / 128) * 128;
+  const int rows = h->slots;
   std::vector<float> dv((size_t)rows * h->np, 0.f), mk((size_t)rows * h->np, 1.f), rh((size_t)rows * h->np, 0.f);
   std::vector<int> fl(rows, 0);
   for (int p = 0; p < B; ++p) {

@@ -68,6 +68,41 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[TileCfg<NB>::MT][TileCfg
                                                               acc[mi][mj], 0, 0, 0);
 }
 
+// Same, but only the 32x32 sub-tiles (mi, mj) for which pred(mi, mj) holds
+// (pred must be wave-uniform): triangular operands skip their zero blocks.
+template <int NB, class Pred>
+__device__ __forceinline__ void mma_chunk_pred(f32x16 (&acc)[TileCfg<NB>::MT][TileCfg<NB>::MT],
+                                               const float* __restrict__ sA,
+                                               const float* __restrict__ sB, int wr, int wc,
+                                               int lane, Pred pred) {
+  constexpr int MT = TileCfg<NB>::MT;
+  constexpr int WT = TileCfg<NB>::WT;
+  const int lr = lane & 31, kh = (lane >> 5) * 16;
+  f32x4 a[MT][4], b[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float* pa = sA + (wr * WT + m * 32 + lr) * LDS_LD + kh;
+    const float* pb = sB + (wc * WT + m * 32 + lr) * LDS_LD + kh;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      a[m][v] = *reinterpret_cast<const f32x4*>(pa + 4 * v);
+      b[m][v] = *reinterpret_cast<const f32x4*>(pb + 4 * v);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int mj = 0; mj < MT; ++mj)
+      if (pred(mi, mj)) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[mi][mj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][v][e], b[mj][v][e],
+                                                                acc[mi][mj], 0, 0, 0);
+      }
+}
+
 // Global -> registers for one operand chunk: rows [0,NB) x k [k0, k0+32).
 // `ld` is the row stride in floats; `g` points at row 0, k = k0.
 template <int NB>
