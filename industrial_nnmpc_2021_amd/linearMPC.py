@@ -1,0 +1,457 @@
+"""Host-side mirror of the reference's ``lib/linearMPC.py`` interface.
+
+Same class / function names, keyword-only constructors, argument meaning and
+column-vector ``(k, 1)`` conventions as the reference, so the module drops in
+under ``lib/controller_evaluation.py`` (which does ``from linearMPC import
+DenseQPRegulator, online_simulation, LinearMPCController, dlqr``).  What
+changes is where the arithmetic of the hot path runs:
+
+* ``DenseQPRegulator.solve`` (reference :495-512 -> cvxopt.solvers.qp) hands
+  the condensed QP to the HIP library (``qp.BatchedBoxQP``); the additive
+  ``solve_batch`` entry point solves B independent (x0, ulb, uub) per call.
+* ``OfflineSimulator.generate_data`` / ``simulate_offline`` (:803-880) advance
+  all chains of a task in lock-step, one batched GPU regulator solve per step,
+  instead of one OS process per chain.
+* the condensed matrices are built by recursion (``condense.py``) instead of
+  the dense block-diagonal stacks (:397-474).
+
+Kalman filter, plant simulator and the small target-selector QP (n = Nx + Nu)
+stay on the host in fp64: they are not on the hot path.
+"""
+import sys
+import time
+
+import numpy as np
+import scipy.linalg
+
+from . import condense
+from .linearMPC_build import dlqr, augmented_matrices_for_regulator
+from .host_qp import solve_small_qp
+
+__all__ = ["dlqr", "dlqe", "c2d", "assert_detectable", "assert_stabilizable",
+           "LinearPlantSimulator", "KalmanFilter", "TargetSelector", "DenseQPRegulator",
+           "LinearMPCController", "online_simulation", "OfflineSimulator", "simulate_offline"]
+
+
+def dlqe(A, C, Q, R):
+    """Discrete-time Kalman filter gain (reference :42-48)."""
+    P = scipy.linalg.solve_discrete_are(A.T, C.T, Q, R)
+    L = scipy.linalg.solve(C @ P @ C.T + R, C @ P).T
+    return (L, P)
+
+
+def c2d(A, B, sample_time):
+    """Zero-order-hold discretisation through one matrix exponential (reference :50-64)."""
+    Nx, Nu = B.shape
+    M = np.zeros((Nx + Nu, Nx + Nu))
+    M[:Nx, :Nx], M[:Nx, Nx:] = A, B
+    E = scipy.linalg.expm(M * sample_time)
+    return (E[:Nx, :Nx], E[:Nx, Nx:])
+
+
+def _unstable_modes_visible(X, Y):
+    w, V = np.linalg.eig(X)
+    for v in V[:, np.abs(w) >= 1.0].T:
+        if np.linalg.norm(Y @ v) <= 1e-8:
+            return False
+    return True
+
+
+def assert_detectable(A, C):
+    """(reference :79-81)"""
+    assert _unstable_modes_visible(A, C)
+
+
+def assert_stabilizable(A, B):
+    """(reference :83-85)"""
+    assert _unstable_modes_visible(A.T, B.T)
+
+
+class LinearPlantSimulator:
+    """Linear plant with measurement noise (reference :87-131)."""
+
+    def __init__(self, *, A, B, C, Bp, Rv, sample_time, x0):
+        self.A, self.B, self.C, self.Bp = A, B, C, Bp
+        self.Nx, self.Nu, self.Ny = A.shape[0], B.shape[1], C.shape[0]
+        self.measurement_noise_std = np.sqrt(np.diag(Rv)[:, np.newaxis])
+        self.sample_time = sample_time
+        self.x, self.u, self.p = [x0], [], []
+        self.v = [self.measurement_noise_std * np.random.randn(self.Ny, 1)]
+        self.y = [self.C @ x0 + self.v[-1]]
+        self.t = [0.]
+
+    def step(self, u, p):
+        x = self.A @ self.x[-1] + self.B @ u + self.Bp @ p
+        v = self.measurement_noise_std * np.random.randn(self.Ny, 1)
+        y = self.C @ x + v
+        self._append_data(x, u, p, v, y)
+        return y
+
+    def _append_data(self, x, u, p, v, y):
+        self.x.append(x); self.u.append(u); self.p.append(p); self.v.append(v); self.y.append(y)
+        self.t.append(self.t[-1] + self.sample_time)
+
+
+class KalmanFilter:
+    """Steady-state Kalman filter (reference :133-176)."""
+
+    def __init__(self, *, A, B, C, Qw, Rv, xprior):
+        self.A, self.B, self.C, self.Qw, self.Rv = A, B, C, Qw, Rv
+        (self.L, _) = dlqe(A, C, Qw, Rv)
+        self.xhat, self.xhat_pred, self.y, self.uprev = [xprior], [], [], []
+
+    def solve(self, y, uprev):
+        xhat_pred = self.A @ self.xhat[-1] + self.B @ uprev
+        xhat = xhat_pred + self.L @ (y - self.C @ xhat_pred)
+        self.xhat.append(xhat); self.xhat_pred.append(xhat_pred); self.y.append(y); self.uprev.append(uprev)
+        return xhat
+
+
+class TargetSelector:
+    """Steady-state target QP (reference :178-319): same (P, q, G, h, A, b) as
+    the reference builds; solved on the host in fp64 (n = Nx + Nu, not the hot path)."""
+
+    def __init__(self, *, A, B, C, H, Bd, Cd, usp, Rs, Qs, ulb, uub, ylb=None, yub=None):
+        self.A, self.B, self.C, self.H, self.Bd, self.Cd, self.Rs, self.Qs = A, B, C, H, Bd, Cd, Rs, Qs
+        self.Nx, self.Nu, self.Ny = A.shape[0], B.shape[1], C.shape[0]
+        self.Nd, self.Nz = Bd.shape[1], H.shape[0]
+        self.usp = usp
+        self.ysp, self.dhats, self.xs, self.us = [], [], [], []
+        self.ulb, self.uub, self.ylb, self.yub = ulb, uub, ylb, yub
+        self._setup_fixed_matrices()
+        self._cache = {}
+
+    def _setup_fixed_matrices(self):
+        Nx, Nu, Ny, Nz = self.Nx, self.Nu, self.Ny, self.Nz
+        E = np.vstack((np.eye(Nu), -np.eye(Nu)))
+        self.F = np.vstack((np.eye(Ny), -np.eye(Ny)))
+        if self.ylb is not None and self.yub is not None:
+            self.G = np.block([[self.F @ self.C, np.zeros((2 * Ny, Nu))], [np.zeros((2 * Nu, Nx)), E]])
+            self.h = None
+        else:
+            self.G = np.hstack((np.zeros((2 * Nu, Nx)), E))
+            self.h = np.vstack((self.uub, -self.ulb))
+        self.tA = np.block([[np.eye(Nx) - self.A, -self.B], [self.H @ self.C, np.zeros((Nz, Nu))]])
+        self.tb = np.block([[np.zeros((Nx, Ny)), self.Bd], [self.H, -(self.H @ self.Cd)]])
+        self.P = scipy.linalg.block_diag(self.C.T @ (self.Qs @ self.C), self.Rs)
+
+    def _setup_changing_matrices(self, ysp, dhats):
+        q = np.vstack((-(self.C.T @ (self.Qs @ (ysp - self.Cd @ dhats))), -(self.Rs @ self.usp)))
+        if self.h is None:
+            h1 = np.vstack((self.yub, -self.ylb)) - self.F @ (self.Cd @ dhats)
+            h = np.vstack((h1, self.uub, -self.ulb))
+        else:
+            h = self.h
+        b = self.tb @ np.vstack((ysp, dhats))
+        return (q, h, b)
+
+    def solve(self, ysp, dhats):
+        """(xs, us) for one (ysp, dhat).  Identical consecutive inputs (piecewise-constant
+        PRBS signals) are answered from a one-entry cache."""
+        key = (ysp.tobytes(), dhats.tobytes())
+        if key not in self._cache:
+            (q, h, b) = self._setup_changing_matrices(ysp, dhats)
+            self._cache = {key: solve_small_qp(self.P, q, self.G, h, self.tA, b)}
+        (xs, us) = np.split(self._cache[key].reshape(-1, 1), [self.Nx])
+        self.xs.append(xs); self.us.append(us); self.ysp.append(ysp); self.dhats.append(dhats)
+        return (xs, us)
+
+
+class DenseQPRegulator:
+    """Condensed regulator QP (reference :321-517) solved on the GPU.
+
+    min 1/2 sum_k (x'Qx + u'Ru + 2x'Mu) + 1/2 x_N' Pf x_N,  x+ = Ax + Bu,  ulb <= u <= uub.
+    """
+
+    def __init__(self, *, A, B, Q, R, M, N, ulb, uub, max_batch=1024, solver_options=None):
+        self.A, self.B, self.Q, self.R, self.M, self.N = A, B, Q, R, M, N
+        self.ulb, self.uub = ulb, uub
+        self.Nx, self.Nu = A.shape[0], B.shape[1]
+        (self.Krep, self.Pf) = dlqr(A, B, Q, R, M)
+        self._reparameterize()
+        (self.P, self.tq) = condense.condense(self.A, self.B, self.Q, self.R, self.M, self.Pf, N)
+        self._max_batch = max_batch
+        self._opts = dict(solver_options or {})
+        self._qp = None
+        self.x0, self.useq = [], []
+        self.last_info = None
+
+    def _reparameterize(self):
+        """u = Kx + v when A is not stable (reference :366-382)."""
+        if np.any(np.abs(np.linalg.eigvals(self.A)) >= 1.0):
+            K = self.Krep
+            self.A = self.A + self.B @ K
+            self.Q = self.Q + K.T @ (self.R @ K) + self.M @ K + K.T @ self.M.T
+            self.M = K.T @ self.R + self.M
+            self.reparameterize = True
+        else:
+            self.reparameterize = False
+
+    # ---- dense views of the reference's fixed matrices (built on demand; small problems only)
+    @property
+    def tE(self):
+        E = np.vstack((np.eye(self.Nu), -np.eye(self.Nu)))
+        return scipy.linalg.block_diag(*([E] * self.N))
+
+    @property
+    def G(self):
+        """Inequality matrix of the dense QP (reference :476-482)."""
+        if self.reparameterize:
+            Mg, _ = condense.constraint_map(self.A, self.B, self.Krep, self.N)
+            return self.tE @ Mg
+        return self.tE
+
+    def _get_h(self, x0):
+        """(reference :484-493)"""
+        te = np.tile(np.vstack((self.uub, -self.ulb)), (self.N, 1))
+        if self.reparameterize:
+            _, KA = condense.constraint_map(self.A, self.B, self.Krep, self.N)
+            return te - self.tE @ (KA @ x0)
+        return te
+
+    def _solver(self):
+        if self.reparameterize:
+            raise NotImplementedError(
+                "re-parameterised (unstable-plant) regulator: the dense-G HIP path is not built yet")
+        if self._qp is None:
+            from .qp import BatchedBoxQP
+            self._qp = BatchedBoxQP(self.P, self.tq, self.Nu, max_batch=self._max_batch, **self._opts)
+        return self._qp
+
+    def solve_batch(self, X0, ulb=None, uub=None, first_move_only=False):
+        """B problems at once.  X0 (B, n_aug); ulb/uub (B, Nu) or (Nu,[1]) (default: self.ulb/uub).
+
+        Returns (U (B, N*Nu) or (B, Nu), info) with info = dict(active (B, 2 N Nu) bool in the
+        row order of G, status (B,), ipm_iters, factorizations).
+        """
+        lb = self.ulb if ulb is None else ulb
+        ub = self.uub if uub is None else uub
+        out = self._solver().solve_batch(np.asarray(X0, float).reshape(-1, self.Nx),
+                                         np.asarray(lb, float).reshape(-1, self.Nu),
+                                         np.asarray(ub, float).reshape(-1, self.Nu))
+        U = out.pop("u")
+        self.last_info = out
+        return (U[:, :self.Nu] if first_move_only else U), out
+
+    def solve(self, x0):
+        """One problem, reference signature: x0 (n_aug, 1) -> useq (N*Nu, 1)  (reference :495-512)."""
+        U, info = self.solve_batch(x0.reshape(1, -1), self.ulb.reshape(1, -1), self.uub.reshape(1, -1))
+        if info["status"][0] == 2:
+            raise ArithmeticError("regulator QP: numerical failure in the KKT factorisation")
+        useq = U.reshape(-1, 1)
+        self._save_data(x0, useq)
+        return useq
+
+    def _save_data(self, x0, useq):
+        self.x0.append(x0)
+        self.useq.append(useq)
+
+
+class LinearMPCController:
+    """Kalman filter + target selector + regulator (reference :519-701)."""
+
+    def __init__(self, *, A, B, C, H, Qwx, Qwd, Rv, xprior, dprior, Rs, Qs, Bd, Cd, usp, uprev,
+                 Q, R, S, ulb, uub, N):
+        self.A, self.B, self.C, self.H = A, B, C, H
+        self.Qwx, self.Qwd, self.Rv, self.xprior, self.dprior = Qwx, Qwd, Rv, xprior, dprior
+        self.Rs, self.Qs, self.Bd, self.Cd, self.usp = Rs, Qs, Bd, Cd, usp
+        self.uprev = uprev
+        self.useq = np.tile(uprev, (N, 1))
+        self.Q, self.R, self.S, self.ulb, self.uub, self.N = Q, R, S, ulb, uub, N
+        self.Nx, self.Nu, self.Ny, self.Nd = A.shape[0], B.shape[1], C.shape[0], Bd.shape[1]
+        self.filter = LinearMPCController.setup_filter(A=A, B=B, C=C, Bd=Bd, Cd=Cd, Qwx=Qwx, Qwd=Qwd, Rv=Rv,
+                                                       xprior=xprior, dprior=dprior)
+        self.target_selector = LinearMPCController.setup_target_selector(A=A, B=B, C=C, H=H, Bd=Bd, Cd=Cd, usp=usp,
+                                                                         Qs=Qs, Rs=Rs, ulb=ulb, uub=uub)
+        self.regulator = LinearMPCController.setup_regulator(A=A, B=B, Q=Q, R=R, S=S, N=N, ulb=ulb, uub=uub)
+        (_, _, self.Qaug, self.Raug, self.Maug) = LinearMPCController.get_augmented_matrices_for_regulator(A, B, Q, R, S)
+        self.average_stage_costs = [np.zeros((1, 1))]
+        self.computation_times = []
+
+    @staticmethod
+    def setup_filter(A, B, C, Bd, Cd, Qwx, Qwd, Rv, xprior, dprior):
+        (Aaug, Baug, Caug, Qwaug) = LinearMPCController.get_augmented_matrices_for_filter(A, B, C, Bd, Cd, Qwx, Qwd)
+        return KalmanFilter(A=Aaug, B=Baug, C=Caug, Qw=Qwaug, Rv=Rv, xprior=np.concatenate((xprior, dprior)))
+
+    @staticmethod
+    def setup_target_selector(A, B, C, H, Bd, Cd, usp, Qs, Rs, ulb, uub):
+        return TargetSelector(A=A, B=B, C=C, H=H, Bd=Bd, Cd=Cd, usp=usp, Rs=Rs, Qs=Qs, ulb=ulb, uub=uub)
+
+    @staticmethod
+    def setup_regulator(A, B, Q, R, S, N, ulb, uub, **kw):
+        (Aaug, Baug, Qaug, Raug, Maug) = LinearMPCController.get_augmented_matrices_for_regulator(A, B, Q, R, S)
+        return DenseQPRegulator(A=Aaug, B=Baug, Q=Qaug, R=Raug, N=N, M=Maug, ulb=ulb, uub=uub, **kw)
+
+    @staticmethod
+    def get_augmented_matrices_for_filter(A, B, C, Bd, Cd, Qwx, Qwd):
+        """Integrating-disturbance augmentation (reference :606-624)."""
+        Nx, Nu, Nd = A.shape[0], B.shape[1], Bd.shape[1]
+        Aaug = np.block([[A, Bd], [np.zeros((Nd, Nx)), np.eye(Nd)]])
+        Baug = np.vstack((B, np.zeros((Nd, Nu))))
+        Caug = np.hstack((C, Cd))
+        Qwaug = scipy.linalg.block_diag(Qwx, Qwd)
+        assert_detectable(Aaug, Caug)
+        return (Aaug, Baug, Caug, Qwaug)
+
+    get_augmented_matrices_for_regulator = staticmethod(augmented_matrices_for_regulator)
+
+    def control_law(self, ysp, y):
+        """Measurement -> input; only the regulator solve is timed (reference :646-669)."""
+        (xhat, dhat) = LinearMPCController.get_state_estimates(self.filter, y, self.uprev, self.Nx)
+        (xs, us) = LinearMPCController.get_target_pair(self.target_selector, ysp, dhat)
+        tstart = time.time()
+        self.useq = LinearMPCController.get_control_sequence(self.regulator, xhat, self.uprev, xs, us,
+                                                             self.ulb, self.uub)
+        tend = time.time()
+        avg_ell = LinearMPCController.get_updated_average_stage_cost(
+            xhat, self.uprev, xs, us, self.useq[0:self.Nu, :], self.Qaug, self.Raug, self.Maug,
+            self.average_stage_costs[-1], len(self.average_stage_costs))
+        self.average_stage_costs.append(avg_ell)
+        self.uprev = self.useq[0:self.Nu, :]
+        self.computation_times.append(tend - tstart)
+        return self.uprev
+
+    @staticmethod
+    def get_state_estimates(filter, y, uprev, Nx):
+        return np.split(filter.solve(y, uprev), [Nx])
+
+    @staticmethod
+    def get_target_pair(target_selector, ysp, dhat):
+        return target_selector.solve(ysp, dhat)
+
+    @staticmethod
+    def get_control_sequence(regulator, x, uprev, xs, us, ulb, uub):
+        """Deviation variables in, absolute input sequence out (reference :682-689)."""
+        regulator.ulb = ulb - us
+        regulator.uub = uub - us
+        x0 = np.concatenate((x - xs, uprev - us))
+        return regulator.solve(x0) + np.tile(us, (regulator.N, 1))
+
+    @staticmethod
+    def get_control_sequence_batch(regulator, X, Uprev, Xs, Us, ulb, uub, first_move_only=True):
+        """Batched counterpart of get_control_sequence: rows are samples (B, .)."""
+        X0 = np.concatenate((X - Xs, Uprev - Us), axis=1)
+        U, info = regulator.solve_batch(X0, ulb.reshape(1, -1) - Us, uub.reshape(1, -1) - Us,
+                                        first_move_only=first_move_only)
+        return U + (Us if first_move_only else np.tile(Us, (1, regulator.N))), info
+
+    @staticmethod
+    def get_updated_average_stage_cost(x, uprev, xs, us, u, Qaug, Raug, Maug, average_stage_cost, time_index):
+        """Running mean of the stage cost (reference :691-701)."""
+        x = np.concatenate((x - xs, uprev - us), axis=0)
+        u = u - us
+        stage_cost = x.T @ (Qaug @ x) + u.T @ (Raug @ u) + x.T @ (Maug @ u) + u.T @ (Maug.T @ x)
+        return (average_stage_cost * (time_index - 1) + stage_cost) / time_index
+
+
+def online_simulation(plant, controller, *, setpoints=None, disturbances=None, Nsim=None, stdout_filename=None):
+    """Closed loop plant <-> controller (reference :703-718)."""
+    if stdout_filename is not None:
+        sys.stdout = open(stdout_filename, 'w')
+    measurement = plant.y[0]
+    setpoints = setpoints[..., np.newaxis]
+    disturbances = disturbances[..., np.newaxis]
+    for (setpoint, disturbance, i) in zip(setpoints, disturbances, range(Nsim)):
+        print("Simulation Step:" + f"{i}")
+        control_input = controller.control_law(setpoint, measurement)
+        print("Computation time:" + str(controller.computation_times[-1]))
+        measurement = plant.step(control_input, disturbance)
+    return plant
+
+
+def _save_training_data(dictionary, filename):
+    """One dataset per key (reference lib/python_utils.py:41-57); .h5 when h5py exists, else .npz."""
+    try:
+        import h5py
+        with h5py.File(filename, "w") as f:
+            for k, v in dictionary.items():
+                f.create_dataset(k, data=v)
+        return filename
+    except ImportError:
+        np.savez(filename + ".npz", **dictionary)
+        return filename + ".npz"
+
+
+def simulate_chains(x0, uprev0, A, B, Bd, regulator, ulb, uub, target_selectors, setpoints, disturbances):
+    """Lock-step closed-loop chains: chain c follows setpoints[c] (T, Ny), disturbances[c] (T, Nd).
+
+    Per step: target pair per chain (host), ONE batched regulator solve for all chains (GPU),
+    model step x+ = A x + B u + Bd d.  Same recurrences and outputs as the reference's
+    simulate_offline (:845-872), which runs one chain per OS process.
+    """
+    nc = len(setpoints)
+    T = setpoints[0].shape[0]
+    Nx, Nu = B.shape
+    X = np.tile(x0.T, (nc, 1))
+    Uprev = np.tile(uprev0.T, (nc, 1))
+    out = dict(x=np.empty((nc, T, Nx)), uprev=np.empty((nc, T, Nu)), xs=np.empty((nc, T, Nx)),
+               us=np.empty((nc, T, Nu)), u=np.empty((nc, T, Nu)))
+    status = np.zeros((nc, T), np.int32)
+    for t in range(T):
+        Xs, Us = np.empty((nc, Nx)), np.empty((nc, Nu))
+        for c in range(nc):
+            (xs, us) = LinearMPCController.get_target_pair(target_selectors[c], setpoints[c][t][:, None],
+                                                           disturbances[c][t][:, None])
+            Xs[c], Us[c] = xs[:, 0], us[:, 0]
+        U, info = LinearMPCController.get_control_sequence_batch(regulator, X, Uprev, Xs, Us, ulb, uub)
+        status[:, t] = info["status"]
+        out["x"][:, t], out["uprev"][:, t], out["xs"][:, t], out["us"][:, t], out["u"][:, t] = X, Uprev, Xs, Us, U
+        D = np.stack([disturbances[c][t] for c in range(nc)])
+        X = X @ A.T + U @ B.T + D @ Bd.T
+        Uprev = U
+    out["status"] = status
+    return out
+
+
+def simulate_offline(task_number, process_number, data_filename, x0, uprev0, A, B, Bd,
+                     regulator, ulb, uub, target_selector, setpoints, disturbances):
+    """One chain, reference signature (:827-880); runs through the batched driver with B = 1."""
+    t0 = time.time()
+    res = simulate_chains(x0, uprev0, A, B, Bd, regulator, ulb, uub, [target_selector], [setpoints], [disturbances])
+    data = {k: res[k][0] for k in ("x", "uprev", "xs", "us", "u")}
+    data["data_gen_time"] = time.time() - t0
+    return _save_training_data(data, str(task_number) + '-' + str(process_number) + '-' + data_filename)
+
+
+class OfflineSimulator:
+    """Offline data generation (reference :720-825): the long PRBS signal is cut into
+    num_data_gen_task * num_process_per_task contiguous chains (_split_scenarios, :786-801);
+    generate_data(task) advances all chains of the task in lock-step on the GPU."""
+
+    def __init__(self, *, A, B, C, H, Rs, Qs, Bd, Cd, usp, uprev, Q, R, S, ulb, uub, N, xprior,
+                 setpoints, disturbances, num_data_gen_task, num_process_per_task):
+        self.A, self.B, self.C, self.H = A, B, C, H
+        self.Rs, self.Qs, self.Bd, self.Cd, self.usp = Rs, Qs, Bd, Cd, usp
+        self.Q, self.R, self.S, self.ulb, self.uub, self.N = Q, R, S, ulb, uub, N
+        self.num_data_gen_task, self.num_process_per_task = num_data_gen_task, num_process_per_task
+        self.Nx, self.Nu, self.Ny, self.Nd = A.shape[0], B.shape[1], C.shape[0], Bd.shape[1]
+        self.x0, self.uprev0 = xprior, uprev
+        # one regulator (the GPU handle is shared by all chains), one target selector per chain
+        self.regulator = LinearMPCController.setup_regulator(A=A, B=B, Q=Q, R=R, S=S, N=N, ulb=ulb, uub=uub)
+        self.regulators = [self.regulator] * num_process_per_task
+        self.target_selectors = [LinearMPCController.setup_target_selector(
+            A=A, B=B, C=C, H=H, Bd=Bd, Cd=Cd, usp=usp, Qs=Qs, Rs=Rs, ulb=ulb, uub=uub)
+            for _ in range(num_process_per_task)]
+        (self.setpoints, self.disturbances) = self._split_scenarios(setpoints=setpoints, disturbances=disturbances)
+
+    def _split_scenarios(self, *, setpoints, disturbances):
+        nt, npp = self.num_data_gen_task, self.num_process_per_task
+        each = int(setpoints.shape[0] / (nt * npp))
+        sp = [setpoints[k * each:(k + 1) * each, :] for k in range(nt * npp)]
+        ds = [disturbances[k * each:(k + 1) * each, :] for k in range(nt * npp)]
+        return ([sp[t * npp:(t + 1) * npp] for t in range(nt)], [ds[t * npp:(t + 1) * npp] for t in range(nt)])
+
+    def generate_data(self, *, task_number, data_filename, stdout_filename=None):
+        """Writes '<task>-<proc>-<data_filename>' per chain, like the reference (:877-880)."""
+        if stdout_filename is not None:
+            sys.stdout = open(stdout_filename, 'w')
+        t0 = time.time()
+        res = simulate_chains(self.x0, self.uprev0, self.A, self.B, self.Bd, self.regulator, self.ulb, self.uub,
+                              self.target_selectors, self.setpoints[task_number], self.disturbances[task_number])
+        dt = time.time() - t0
+        files = []
+        for proc in range(self.num_process_per_task):
+            data = {k: res[k][proc] for k in ("x", "uprev", "xs", "us", "u")}
+            data["data_gen_time"] = dt
+            files.append(_save_training_data(data, str(task_number) + '-' + str(proc) + '-' + data_filename))
+        return files

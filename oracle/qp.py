@@ -275,3 +275,73 @@ def solve_exact_box(P, q, lb, ub, tol=1e-11, maxiters=80, info=None):
             rows[k * 2 * nu + nu + c] = al
             info["active"] = np.flatnonzero(rows)
     return x
+
+
+def solve_exact_eq(P, q, G, h, A, b, tol=1e-11, maxiters=100, info=None):
+    """Exact optimum of  min 1/2 x'Px + q'x  s.t. Gx <= h, Ax = b   (P >= 0 allowed).
+
+    The target-selector QP of the reference (lib/linearMPC.py:298-311) has this
+    form (cvxopt.solvers.qp(P, q, G, h, A, b), :304-305).  Dense KKT solves;
+    meant for the small fixtures / the chain-driver golden only.
+    """
+    P = _sym_lower(np.asarray(P, float))
+    q = np.asarray(q, float).reshape(-1)
+    G = np.asarray(G, float)
+    h = np.asarray(h, float).reshape(-1)
+    A = np.asarray(A, float)
+    b = np.asarray(b, float).reshape(-1)
+    n, m, pe = q.size, h.size, b.size
+
+    def kkt_solve(d, r1, r2):
+        K = np.block([[P + G.T @ (d[:, None] * G), A.T], [A, np.zeros((pe, pe))]])
+        sol = np.linalg.solve(K, np.concatenate((r1, r2)))
+        return sol[:n], sol[n:]
+
+    x, y = kkt_solve(np.ones(m), -q + G.T @ h, b)
+    s = np.maximum(h - G @ x, 1.0)
+    z = np.ones(m)
+    for _ in range(maxiters):
+        rx = P @ x + q + G.T @ z + A.T @ y
+        ry = A @ x - b
+        rz = s + G @ x - h
+        gap = float(s @ z)
+        if max(np.abs(rx).max(), np.abs(ry).max() if pe else 0.0, np.abs(rz).max(), gap) <= tol:
+            break
+        d = z / s
+        mu, sigma, dsa, dza = gap / m, 0.0, None, None
+        for i in (0, 1):
+            rc = -s * z + sigma * mu - (dsa * dza if i else 0.0)
+            dx, dy = kkt_solve(d, -rx - G.T @ ((rc + z * rz) / s), -ry)
+            ds = -rz - G @ dx
+            dz = (rc - z * ds) / s
+            t = max(0.0, np.max(-ds / s), np.max(-dz / z))
+            if i == 0:
+                a = 1.0 if t == 0 else min(1.0, 1.0 / t)
+                dsa, dza = ds, dz
+                sigma = min(1.0, max(0.0, 1.0 - a + float(ds @ dz) / gap * a * a)) ** 3
+            else:
+                a = 1.0 if t == 0 else min(1.0, 0.995 / t)
+        xn, yn, sn, zn = x + a * dx, y + a * dy, s + a * ds, z + a * dz
+        if not (np.all(np.isfinite(xn)) and np.all(sn > 0) and np.all(zn > 0)):
+            break                     # fp64 floor reached; the polish below finishes the job
+        x, y, s, z = xn, yn, sn, zn
+    # polish on the active inequality rows
+    act = z > s
+    for _ in range(50):
+        idx = np.flatnonzero(act)
+        Ae = np.vstack((A, G[idx]))
+        be = np.concatenate((b, h[idx]))
+        K = np.block([[P, Ae.T], [Ae, np.zeros((Ae.shape[0],) * 2)]])
+        sol = np.linalg.lstsq(K, np.concatenate((-q, be)), rcond=None)[0]
+        xn = sol[:n]
+        lam = np.zeros(m)
+        lam[idx] = sol[n + pe:]
+        slack = h - G @ xn
+        new_act = (act & (lam > 0.0)) | (~act & (slack < -1e-12 * (1 + np.abs(h))))
+        x = xn
+        if np.array_equal(new_act, act):
+            break
+        act = new_act
+    if info is not None:
+        info.update(active=np.flatnonzero(act))
+    return x

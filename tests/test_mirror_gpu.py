@@ -1,0 +1,130 @@
+"""GPU parity of the reference-interface mirror (DenseQPRegulator / get_control_sequence /
+simulate_offline / cvxopt-shaped qp / NN layers) against the golden vectors the
+reference itself produced (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("case", ["stable_s0", "stable_s1"])
+def test_get_control_sequence_matches_reference_golden(golden_dir, case):
+    from industrial_nnmpc_2021_amd import linearMPC as lm
+    g, e = _load(golden_dir, f"regulator_{case}.npz"), _load(golden_dir, f"qp_exact_{case}.npz")
+    reg = lm.LinearMPCController.setup_regulator(g["A"], g["B"], g["Q"], g["R"], g["S"], int(g["N"]), g["ulb"], g["uub"],
+                                                 max_batch=128)
+    nb = g["x0"].shape[0]
+    for b in range(nb):                       # reference call path, one problem at a time
+        useq = lm.LinearMPCController.get_control_sequence(reg, g["x"][b], g["uprev"][b], g["xs"][b], g["us"][b],
+                                                           g["ulb"], g["uub"])
+        assert useq.shape == e["useq"][b].shape
+        assert np.abs(useq - e["useq"][b]).max() <= 1e-8 * max(1.0, np.abs(useq).max())
+        assert np.array_equal(reg.last_info["active"][0], e["active"][b])
+    assert len(reg.x0) == nb and len(reg.useq) == nb
+    # batched entry point, all problems in one call
+    U, info = lm.LinearMPCController.get_control_sequence_batch(
+        reg, g["x"][:, :, 0], g["uprev"][:, :, 0], g["xs"][:, :, 0], g["us"][:, :, 0], g["ulb"], g["uub"],
+        first_move_only=False)
+    assert (info["status"] == 0).all()
+    assert np.abs(U - e["useq"][:, :, 0]).max() <= 1e-8 * max(1.0, np.abs(U).max())
+    assert np.array_equal(info["active"], e["active"])
+
+
+def test_unstable_plant_is_refused_loudly(golden_dir):
+    from industrial_nnmpc_2021_amd import linearMPC as lm
+    g = _load(golden_dir, "regulator_unstable_s0.npz")
+    reg = lm.LinearMPCController.setup_regulator(g["A"], g["B"], g["Q"], g["R"], g["S"], int(g["N"]), g["ulb"], g["uub"])
+    assert reg.reparameterize
+    with pytest.raises(NotImplementedError):
+        reg.solve(g["x0"][0])
+
+
+def test_offline_simulator_matches_reference_chain(golden_dir, tmp_path, monkeypatch):
+    from industrial_nnmpc_2021_amd import linearMPC as lm
+    g = _load(golden_dir, "chain.npz")
+    nu, Nx = g["B"].shape[1], g["A"].shape[0]
+    sim = lm.OfflineSimulator(A=g["A"], B=g["B"], C=g["C"], H=g["H"], Rs=g["Rs"], Qs=g["Qs"], Bd=g["Bd"], Cd=g["Cd"],
+                              usp=np.zeros((nu, 1)), uprev=np.zeros((nu, 1)), Q=g["Q"], R=g["R"], S=g["S"],
+                              ulb=g["ulb"], uub=g["uub"], N=int(g["N"]), xprior=np.zeros((Nx, 1)),
+                              setpoints=g["setpoints"], disturbances=g["disturbances"],
+                              num_data_gen_task=1, num_process_per_task=2)   # both chains in lock-step
+    monkeypatch.chdir(tmp_path)
+    files = sim.generate_data(task_number=0, data_filename="chain_data")
+    assert len(files) == 2
+    for c, f in enumerate(files):
+        if f.endswith(".npz"):
+            d = np.load(f)
+        else:
+            import h5py
+            with h5py.File(f, "r") as h:
+                d = {k: h[k][()] for k in h}
+        for k in ("x", "uprev", "xs", "us", "u"):
+            assert d[k].shape == g[f"{k}_{c}"].shape
+            assert np.abs(d[k] - g[f"{k}_{c}"]).max() < 1e-7, (c, k)
+        assert float(d["data_gen_time"]) > 0
+
+
+def test_cvxopt_shaped_qp_seam(golden_dir):
+    """qp(P, q, G, h) with the reference's dense box G, and the equality form of the target selector."""
+    from industrial_nnmpc_2021_amd import cvxopt_shim as cvx
+    g, e = _load(golden_dir, "regulator_stable_s1.npz"), _load(golden_dir, "qp_exact_stable_s1.npz")
+    for b in range(3):
+        sol = cvx.solvers.qp(*[cvx.matrix(a) for a in (g["P"], g["q"][b], g["G"], g["h"][b])])
+        x = np.asarray(sol["x"])
+        assert x.shape == (g["P"].shape[0], 1) and sol["status"] == "optimal"
+        assert np.abs(x[:, 0] - e["v"][b]).max() <= 1e-8 * max(1.0, np.abs(e["v"][b]).max())
+    gu = _load(golden_dir, "regulator_unstable_s0.npz")
+    with pytest.raises(NotImplementedError):
+        cvx.solvers.qp(gu["P"], gu["q"][0], gu["G"], gu["h"][0])
+
+
+@pytest.mark.parametrize("name", ["with_uprev", "without_uprev"])
+def test_nn_layers_match_reference_golden(golden_dir, name):
+    from industrial_nnmpc_2021_amd.LinearMPCLayers import RegulatorLayerWithUprev, RegulatorLayerWithoutUprev
+    from industrial_nnmpc_2021_amd.nn import StructuredNN
+    g = _load(golden_dir, f"nn_{name}.npz")
+    W = [g[f"W{i}"] for i in range(int(g["nW"]))]
+    nx, nu, withu = int(g["nx"]), int(g["nu"]), bool(g["withuprev"])
+    # controller form: scaling + clipping (NeuralNetworkController._get_control_input)
+    net = StructuredNN(W, nx, nu, nnwithuprev=withu, xscale=g["xscale"], ulb=g["ulb"], uub=g["uub"], max_batch=128)
+    u = net.forward(g["x"], g["uprev"], g["xs"], g["us"])
+    assert np.abs(u - g["u"]).max() < 2e-5          # f32 MFMA arithmetic vs the reference's f64
+    assert np.abs(u[0] - np.clip(g["us"][0], -1, 1)).max() < 1e-12   # steady-state row is exact
+    # Keras-layer form: no scaling, no clipping
+    from oracle import nn as onn
+    layer = (RegulatorLayerWithUprev if withu else RegulatorLayerWithoutUprev)([w.shape[1] for w in W[0:-1:2]] + [nu])
+    layer.set_weights(W)
+    inputs = [g["x"], g["uprev"], g["xs"], g["us"]] if withu else [g["x"], g["xs"], g["us"]]
+    out = layer.call(inputs)
+    ref = onn.control_input(W, g["x"], g["uprev"], g["xs"], g["us"], None, None, None, withu)
+    assert np.abs(out - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_nn_cdu_shape_batch_vs_oracle():
+    """[536, 832, 832, 832, 32] WithoutUprev (the architecture the reference trains for the CDU,
+    cdu_train.py:77-80), ragged batch size, f32 tolerance stated: 1e-4 relative."""
+    from industrial_nnmpc_2021_amd.nn import StructuredNN
+    from oracle import nn as onn
+    rng = np.random.default_rng(3)
+    nx, nu, hid = 252, 32, 832
+    dims = [2 * nx + nu, hid, hid, hid, nu]
+    W = []
+    for i in range(4):
+        W.append(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i]))
+        if i < 3:
+            W.append(0.05 * rng.standard_normal(dims[i + 1]))
+    B = 1000
+    x, xs = rng.standard_normal((B, nx)), 0.3 * rng.standard_normal((B, nx))
+    us = rng.uniform(-.5, .5, (B, nu))
+    xscale = rng.uniform(0.5, 2.0, nx)
+    net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu), max_batch=512)
+    u = net.forward(x, None, xs, us)
+    ref = onn.control_input(W, x, None, xs, us, xscale, -np.ones(nu), np.ones(nu), False)
+    assert np.abs(u - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert net.forward(x[:0], None, xs[:0], us[:0]).shape == (0, nu)      # empty batch
