@@ -39,15 +39,20 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_k(float* __restrict__ C, size
       }
 }
 
-// M, N multiples of 64, K multiple of 16.
+// M, N multiples of 64, K multiple of 16.  rowphase (nullable): per-row tag, see below.
 static __global__ __launch_bounds__(256) void gemm_nt_f64_k(double* __restrict__ C, size_t ldc,
                                                      const double* __restrict__ A, size_t lda,
                                                      const double* __restrict__ B, size_t ldb,
-                                                     int K) {
+                                                     int K, const int* __restrict__ rowphase,
+                                                     int want) {
   __shared__ double As[16][65];
   __shared__ double Bs[16][65];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  if (rowphase) {  // skip 64-row blocks in which no row (= solver slot) is in phase `want`
+    const int need = tid < 64 ? (rowphase[m0 + tid] == want) : 0;
+    if (!__syncthreads_or(need)) return;
+  }
   double c[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)

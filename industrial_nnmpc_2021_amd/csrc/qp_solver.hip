@@ -34,7 +34,7 @@ namespace {
 
 enum { PH_INIT = 0, PH_IPM = 1, PH_POLISH = 2, PH_DONE = 3 };
 enum { PS_START = 0, PS_CG = 1, PS_CHECK = 2 };
-enum { CNT_ACTIVE = 0, CNT_FACTOR = 1, CNT_IPM = 2, CNT_POLISH = 3, CNT_SOLVE1 = 4, CNT_PS1 = 5 };
+enum { CNT_ACTIVE = 0, CNT_FACTOR = 1, CNT_IPM = 2, CNT_POLISH = 3, CNT_SOLVE = 4 };
 
 struct QpDev {
   int n, np, nu, slots;
@@ -53,7 +53,7 @@ struct QpDev {
   const float* uunc_all;                      // [seg][np]
   int *slot_prob, *age, *next_prob;
   int seg_count, max_rounds;
-  int *phase, *f_factor, *f_solve1, *f_solve2, *ipm_it, *nfac, *prounds, *rcnt, *psub, *fail;
+  int *phase, *f_factor, *f_solve, *istep, *ipm_it, *nfac, *prounds, *rcnt, *psub, *fail;
   float *mu, *gap, *smu, *qscale;
   double* rz;
   int* counters;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void refill_k(QpDev d) {
     d.age[p] = 0;
     d.qscale[p] = fmaxf(1.f, qm);
     d.phase[p] = PH_INIT;
-    d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
+    d.f_factor[p] = d.f_solve[p] = 0;
     d.ipm_it[p] = d.nfac[p] = d.prounds[p] = d.rcnt[p] = d.psub[p] = d.fail[p] = 0;
     d.mu[p] = d.gap[p] = d.smu[p] = 0.f; d.rz[p] = 0.0;
   }
@@ -172,7 +172,7 @@ __global__ void reset_slots_k(QpDev d) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < d.slots) {
     d.phase[p] = PH_DONE; d.slot_prob[p] = -1; d.age[p] = 0;
-    d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
+    d.f_factor[p] = d.f_solve[p] = 0;
   }
   if (p == 0) *d.next_prob = 0;
 }
@@ -267,6 +267,56 @@ __device__ void cg_beta(const QpDev& d, int p, double* shd) {
   if (tid == 0) { d.rz[p] = rzn; d.psub[p] = PS_CG; }
 }
 
+// fp64 KKT check of the refined point (PX = P x).  Returns 1 when the slot is finished
+// (outputs written, phase DONE); otherwise the active set has been updated, x snapped to
+// the new bounds, psub = START, v = x.
+__device__ int kkt_check(const QpDev& d, int p, int* shi, double* shd) {
+  const int tid = threadIdx.x, n = d.n;
+  const size_t o = (size_t)p * d.np;
+  int bad = 0;
+  double gfree = 0.0;
+  for (int r = tid; r < n; r += 256) {
+    const int c = r % d.nu;
+    const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
+    const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
+    const int s = d.st[o + r];
+    if (s == 0) { bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); gfree = fmax(gfree, fabs(g)); }
+    else if (s == 1) bad += (g >= 0.0);   // multiplier -g must be > 0
+    else bad += (g <= 0.0);               // multiplier  g must be > 0
+  }
+  bad = block_sum_i(bad, shi);
+  gfree = block_maxd(gfree, shd);
+  const int pr = d.prounds[p] + 1;
+  if (bad == 0 || pr > d.max_polish) {
+    // stationarity of the free block certifies the refinement itself
+    const double gs = d.pscale * (double)d.qscale[p];
+    const int ok = bad == 0 && gfree <= d.stat_tol * gs;
+    write_outputs(d, p, ok ? NNMPC_ST_OPTIMAL : NNMPC_ST_MAXITER);
+    if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve[p] = 0; }
+    return 1;
+  }
+  for (int r = tid; r < n; r += 256) {
+    const int c = r % d.nu;
+    const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
+    const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
+    const int s = d.st[o + r];
+    double xn = x;
+    if (s == 0) {
+      if (x > ub + d.bound_tol) { d.st[o + r] = 1; xn = ub; }
+      else if (x < lb - d.bound_tol) { d.st[o + r] = 2; xn = lb; }
+    } else if ((s == 1 && g >= 0.0) || (s == 2 && g <= 0.0)) {
+      d.st[o + r] = 0;
+    }
+    d.x[o + r] = xn;
+    d.v64[o + r] = xn;
+  }
+  if (tid == 0) {
+    d.prounds[p] = pr; d.psub[p] = PS_START; d.rcnt[p] = 0;
+    d.f_factor[p] = d.f_solve[p] = 0;
+  }
+  return 0;
+}
+
 // Round stage 1: needs PU = P u (f32) for INIT/IPM slots, PX = P x (f64) for POLISH slots.
 __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
   __shared__ float shf[4];
@@ -287,7 +337,7 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
         __syncthreads();
       }
       write_outputs(d, p, NNMPC_ST_MAXITER);
-      if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
+      if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve[p] = 0; }
       return;
     }
   }
@@ -336,9 +386,9 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
         d.phase[p] = PH_IPM;
         d.gap[p] = gs; d.mu[p] = mu;
         d.ipm_it[p] = it + 1; d.nfac[p] += 1;
-        d.f_factor[p] = 1; d.f_solve1[p] = 1; d.f_solve2[p] = 1;
+        d.f_factor[p] = 1; d.f_solve[p] = 1; d.istep[p] = 0;
         atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_FACTOR], 1);
-        atomicAdd(&d.counters[CNT_IPM], 1); atomicAdd(&d.counters[CNT_SOLVE1], 1);
+        atomicAdd(&d.counters[CNT_IPM], 1); atomicAdd(&d.counters[CNT_SOLVE], 1);
       }
       return;
     }
@@ -363,63 +413,18 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
     if (tid == 0) {
       if (nan) d.fail[p] = 1;
       d.phase[p] = PH_POLISH; d.psub[p] = PS_START; d.rcnt[p] = 0; d.prounds[p] = 0;
-      d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;
+      d.f_factor[p] = d.f_solve[p] = 0;
       atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
     }
     return;
   }
 
   // ---- PH_POLISH (PX = P64 * v64, v = x in START / CHECK, v = p in CG)
-  const int sub = d.psub[p];
+  int sub = d.psub[p];
   if (sub == PS_CHECK) {
-    // KKT check on the refined point, g = P x + q in f64
-    int bad = 0;
-    double gfree = 0.0;
-    for (int r = tid; r < n; r += 256) {
-      const int c = r % d.nu;
-      const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
-      const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
-      const int s = d.st[o + r];
-      if (s == 0) { bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); gfree = fmax(gfree, fabs(g)); }
-      else if (s == 1) bad += (g >= 0.0);   // multiplier -g must be > 0
-      else bad += (g <= 0.0);               // multiplier  g must be > 0
-    }
-    bad = block_sum_i(bad, shi);
-    gfree = block_maxd(gfree, shd);
-    if (bad == 0) {
-      // stationarity of the free block certifies the refinement itself
-      const double gs = d.pscale * (double)d.qscale[p];
-      write_outputs(d, p, gfree <= d.stat_tol * gs ? NNMPC_ST_OPTIMAL : NNMPC_ST_MAXITER);
-      if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
-      return;
-    }
-    const int pr = d.prounds[p] + 1;
-    if (pr > d.max_polish) {
-      write_outputs(d, p, NNMPC_ST_MAXITER);
-      if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0; }
-      return;
-    }
-    for (int r = tid; r < n; r += 256) {
-      const int c = r % d.nu;
-      const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
-      const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
-      const int s = d.st[o + r];
-      double xn = x;
-      if (s == 0) {
-        if (x > ub + d.bound_tol) { d.st[o + r] = 1; xn = ub; }
-        else if (x < lb - d.bound_tol) { d.st[o + r] = 2; xn = lb; }
-      } else if ((s == 1 && g >= 0.0) || (s == 2 && g <= 0.0)) {
-        d.st[o + r] = 0;
-      }
-      d.x[o + r] = xn;
-      d.v64[o + r] = xn;
-    }
-    if (tid == 0) {
-      d.prounds[p] = pr; d.psub[p] = PS_START; d.rcnt[p] = 0;
-      d.f_factor[p] = d.f_solve1[p] = d.f_solve2[p] = 0;  // P x is stale: restart next round
-      atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
-    }
-    return;
+    if (kkt_check(d, p, shi, shd)) return;          // DONE (outputs written)
+    if (tid == 0) { atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1); }
+    return;                                         // new active set: P x is stale, restart next round
   }
   if (sub == PS_START) {
     // new active set: r = -(P x + q)_F, factor the masked (regularised) P, z = M^-1 r
@@ -432,36 +437,37 @@ __global__ __launch_bounds__(256) void stage_pre_k(QpDev d) {
       d.dvec[o + r] = s ? 1.f : d.delta;
     }
     if (tid == 0) {
-      d.f_factor[p] = 1; d.f_solve1[p] = 1; d.f_solve2[p] = 0;
+      d.f_factor[p] = 1; d.f_solve[p] = 1;
       d.nfac[p] += 1;
       atomicAdd(&d.counters[CNT_FACTOR], 1);
       atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
-      atomicAdd(&d.counters[CNT_SOLVE1], 1); atomicAdd(&d.counters[CNT_PS1], 1);
+      atomicAdd(&d.counters[CNT_SOLVE], 1);
     }
     return;
   }
-  // PS_CG: PX = P p
-  const int go = cg_alpha(d, p, shd);
+  // PS_CG carried over from the previous round: the sub-step loop always stops after part B,
+  // i.e. the slot is waiting for the next preconditioner solve (rhs = r is already in place).
   if (tid == 0) {
-    d.f_factor[p] = 0; d.f_solve1[p] = go; d.f_solve2[p] = 0;
+    d.f_factor[p] = 0; d.f_solve[p] = 1;
     atomicAdd(&d.counters[CNT_ACTIVE], 1); atomicAdd(&d.counters[CNT_POLISH], 1);
-    if (go) { atomicAdd(&d.counters[CNT_SOLVE1], 1); atomicAdd(&d.counters[CNT_PS1], 1); }
+    atomicAdd(&d.counters[CNT_SOLVE], 1);
   }
 }
 
-// Round stage 2 (after solve #1).
-__global__ __launch_bounds__(256) void stage_mid_k(QpDev d) {
+// Solve sub-step, part A (after a triangular solve): sol = K^-1 rhs is available.
+//   IPM  step 0: affine direction -> sigma -> corrector rhs (another solve follows)
+//        step 1: combined direction -> step length -> new iterate (done for this round)
+//   POLISH: z = sol -> new CG direction p, v = p (P p is computed next)
+__global__ __launch_bounds__(256) void stage_sub_a_k(QpDev d) {
   __shared__ float shf[4];
   __shared__ double shd[4];
   const int p = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)p * d.np;
-  if (!d.f_solve1[p]) return;
+  if (!d.f_solve[p]) return;
   const int ph = d.phase[p], n = d.n;
-  if (ph == PH_POLISH) {
-    cg_beta(d, p, shd);
-    if (tid == 0) d.f_solve2[p] = 1;   // second CG half-step of this round
-    return;
-  }
+  if (ph == PH_POLISH) { cg_beta(d, p, shd); return; }
+  if (ph != PH_IPM) return;
+  if (d.istep[p] == 0) {
   // IPM: affine (predictor) direction -> sigma -> corrector right-hand side
   float t = 0.f;
   for (int r = tid; r < n; r += 256) {
@@ -490,28 +496,9 @@ __global__ __launch_bounds__(256) void stage_mid_k(QpDev d) {
     d.rhs[o + r] = -d.rd[o + r] + zu - smu / su - du * dzu / su - zl + smu / sl - du * dzl / sl;
     d.dua[o + r] = du;
   }
-  if (tid == 0) d.smu[p] = smu;
-}
-
-// Round stage 2b: polish slots that take a second refinement solve this round
-// (PX was recomputed from the updated x).
-__global__ __launch_bounds__(256) void stage_mid2_k(QpDev d) {
-  __shared__ double shd[4];
-  const int p = blockIdx.x, tid = threadIdx.x;
-  if (d.phase[p] != PH_POLISH || !d.f_solve1[p] || !d.f_solve2[p]) return;
-  const int go = cg_alpha(d, p, shd);
-  if (tid == 0) d.f_solve2[p] = go;
-}
-
-// Round stage 3 (after solve #2).
-__global__ __launch_bounds__(256) void stage_post_k(QpDev d) {
-  __shared__ float shf[4];
-  __shared__ double shd[4];
-  const int p = blockIdx.x, tid = threadIdx.x;
-  const size_t o = (size_t)p * d.np;
-  if (!d.f_solve2[p]) return;
-  const int ph = d.phase[p], n = d.n;
-  if (ph == PH_POLISH) { cg_beta(d, p, shd); return; }
+  if (tid == 0) { d.smu[p] = smu; d.istep[p] = 1; }
+    return;
+  }
   const float smu = d.smu[p];
   float t = 0.f;
   for (int r = tid; r < n; r += 256) {
@@ -533,6 +520,24 @@ __global__ __launch_bounds__(256) void stage_post_k(QpDev d) {
     d.u[o + r] = u + a * du;
     d.zu[o + r] = fmaxf(zu + a * dzu, 1e-30f);
     d.zl[o + r] = fmaxf(zl + a * dzl, 1e-30f);
+  }
+  if (tid == 0) d.f_solve[p] = 0;
+}
+
+// Solve sub-step, part B (after PX = P v):  POLISH slots only.
+//   CG    : x += a p, r -= a P p; converged -> psub = CHECK, v = x (P x is computed next)
+//   CHECK : (P x fresh) fp64 KKT check -> DONE, or new active set for the next round
+__global__ __launch_bounds__(256) void stage_sub_b_k(QpDev d) {
+  __shared__ int shi[4];
+  __shared__ double shd[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (d.phase[p] != PH_POLISH) return;
+  const int sub = d.psub[p];
+  if (sub == PS_CG && d.f_solve[p]) {
+    const int go = cg_alpha(d, p, shd);
+    if (tid == 0) d.f_solve[p] = go;
+  } else if (sub == PS_CHECK) {
+    kkt_check(d, p, shi, shd);
   }
 }
 
@@ -654,9 +659,9 @@ void gemm32(nnmpc_qp* h, float* C, size_t ldc, const float* A, size_t lda, const
   else launch_gemm32<64>(h->stream, C, ldc, A, lda, B, ldb, M, N, K);
 }
 void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, const double* B,
-            size_t ldb, int M, int N, int K) {
+            size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0) {
   dim3 grid(N / 64, M / 64);
-  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K);
+  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want);
 }
 
 template <int NB>
@@ -741,7 +746,7 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
       any_ipm = true;
     }
     if (any_ipm) gemm32(h, d.PU, h->np, d.u, h->np, h->P32, h->np, rows, h->np, h->np);
-    if (any_polish) gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np);
+    if (any_polish) gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np, d.phase, PH_POLISH);
     hipLaunchKernelGGL(stage_pre_k, dim3(rows), dim3(256), 0, s, d);
     HIPCHK(hipMemcpyAsync(cnt, d.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&issued, d.next_prob, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -753,15 +758,18 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
     h->stats.factorizations += cnt[CNT_FACTOR];
     h->stats.ipm_iterations += cnt[CNT_IPM];
     if (cnt[CNT_FACTOR] > 0) factor_dispatch(h, rows, cnt[CNT_FACTOR]);
-    if (cnt[CNT_SOLVE1] > 0) {
-      solve_dispatch(h, rows, d.f_solve1);
-      hipLaunchKernelGGL(stage_mid_k, dim3(rows), dim3(256), 0, s, d);
-      if (cnt[CNT_PS1] > 0) {
-        gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np);
-        hipLaunchKernelGGL(stage_mid2_k, dim3(rows), dim3(256), 0, s, d);
+    if (cnt[CNT_SOLVE] > 0) {
+      // solve sub-steps: the two PDIP solves, and PCG steps + KKT check of polishing slots, all
+      // inside the round of their factorisation (slots not concerned exit at once)
+      const int nsub = cnt[CNT_POLISH] > 0 ? h->opts.sub_steps : 2;
+      for (int k = 0; k < nsub; ++k) {
+        solve_dispatch(h, rows, d.f_solve);
+        hipLaunchKernelGGL(stage_sub_a_k, dim3(rows), dim3(256), 0, s, d);
+        if (cnt[CNT_POLISH] > 0) {
+          gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np, d.phase, PH_POLISH);
+          hipLaunchKernelGGL(stage_sub_b_k, dim3(rows), dim3(256), 0, s, d);
+        }
       }
-      solve_dispatch(h, rows, d.f_solve2);
-      hipLaunchKernelGGL(stage_post_k, dim3(rows), dim3(256), 0, s, d);
     }
   }
   HIPCHK(hipStreamSynchronize(s));
@@ -798,6 +806,8 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.max_polish_rounds <= 0) o.max_polish_rounds = 12;
   if (o.max_refine <= 0) o.max_refine = 60;
   if (o.max_rounds <= 0) o.max_rounds = 120;
+  if (o.sub_steps <= 0) o.sub_steps = 8;
+  if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
   if (o.refine_tol <= 0.0) o.refine_tol = 1e-10;
   if (o.bound_tol <= 0.0) o.bound_tol = 1e-9;
@@ -829,7 +839,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.u, V); A_(d.zu, V); A_(d.zl, V); A_(d.lbv, V); A_(d.ubv, V); A_(d.q, V); A_(d.PU, V);
   A_(d.rd, V); A_(d.rhs, V); A_(d.sol, V); A_(d.dua, V); A_(d.dvec, V); A_(d.mask, V); A_(d.uunc, V);
   A_(d.x, V); A_(d.q64, V); A_(d.PX, V); A_(d.r64, V); A_(d.p64, V); A_(d.v64, V); A_(d.st, V);
-  A_(d.phase, S); A_(d.f_factor, S); A_(d.f_solve1, S); A_(d.f_solve2, S); A_(d.ipm_it, S);
+  A_(d.phase, S); A_(d.f_factor, S); A_(d.f_solve, S); A_(d.istep, S); A_(d.ipm_it, S);
   A_(d.nfac, S); A_(d.prounds, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.rz, S);
   A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
   {
