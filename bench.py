@@ -53,12 +53,75 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s=30.0):
             "paper_reference": "35 s/solve mean on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"}
 
 
+def bench_nn(args, torch, dev, rank, world, dist):
+    """Config 5: structured-NN controller forward, CDU architecture [536, 832, 832, 832, 32]
+    (RegulatorLayerWithoutUprev, cdu_train.py:33, :77-80), B states per GPU per step, f32 and bf16."""
+    from industrial_nnmpc_2021_amd.nn import StructuredNN
+    from oracle import nn as onn
+    nx, nu, hid = 252, 32, 832
+    dims = [2 * nx + nu, hid, hid, hid, nu]
+    rng = np.random.default_rng(0)
+    W = []
+    for i in range(4):
+        W.append(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i]))
+        if i < 3:
+            W.append(0.05 * rng.standard_normal(dims[i + 1]))
+    B = args.batch or (1 << 20)
+    xscale = rng.uniform(0.5, 2.0, nx)
+    g = torch.Generator(device=dev); g.manual_seed(1000 + rank)
+    x = torch.randn((B, nx), dtype=torch.float64, device=dev, generator=g)
+    xs = 0.3 * torch.randn((B, nx), dtype=torch.float64, device=dev, generator=g)
+    us = torch.rand((B, nu), dtype=torch.float64, device=dev, generator=g) - 0.5
+    u = torch.empty((B, nu), dtype=torch.float64, device=dev)
+    flops_per_state = 2 * 2 * sum(dims[i] * dims[i + 1] for i in range(4))   # both passes
+    res = {}
+    for mode in ("f32", "bf16"):
+        net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu),
+                           max_batch=65536, use_bf16=(mode == "bf16"))
+        for _ in range(args.warmup):
+            net.forward_device(B, x, None, xs, us, u)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter(); gm = 0.0
+        for _ in range(args.steps):
+            net.forward_device(B, x, None, xs, us, u)
+            gm += net.last_ms()[0]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        k = 512
+        ref = onn.control_input(W, x[:k].cpu().numpy(), None, xs[:k].cpu().numpy(), us[:k].cpu().numpy(), xscale,
+                                -np.ones(nu), np.ones(nu), False)
+        err = float(np.abs(u[:k].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()))
+        res[mode] = dict(states_per_s=world * B * args.steps / dt, ms_per_step=1e3 * dt / args.steps,
+                         gemm_TFLOPs=flops_per_state * B * args.steps / (gm * 1e-3) / 1e12, max_rel_err_vs_fp64_oracle=err)
+        net.close()
+    if rank == 0:
+        f = res["f32"]
+        out = {"metric": "structured-NN forward states/sec (CDU architecture)", "value": f["states_per_s"], "unit": "states/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": f["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"cdu_neural_network: RegulatorLayerWithoutUprev {dims}, {B} states per GPU per step",
+                          "flops_per_state": flops_per_state},
+               "roofline": {"kernel": "gemm_nt_f32_k", "bound": "mfma", "achieved": f["gemm_TFLOPs"], "peak": FP32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": f["gemm_TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": None},
+               "parity": {"max_rel_err_vs_fp64_oracle": f["max_rel_err_vs_fp64_oracle"]},
+               "bf16": dict(res["bf16"], peak_TFLOPs=2500.0, frac=res["bf16"]["gemm_TFLOPs"] / 2500.0)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cdu", choices=["cdu", "cstrs"])
+    ap.add_argument("--workload", default="cdu", choices=["cdu", "cstrs", "nn"])
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step")
     ap.add_argument("--slots", type=int, default=0, help="resident problems per wave")
     ap.add_argument("--sx", type=float, default=2.0, help="state spread of the synthetic samples")
@@ -82,6 +145,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "nn":
+        return bench_nn(args, torch, dev, rank, world, dist)
     from industrial_nnmpc_2021_amd import synthetic
     from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
     from industrial_nnmpc_2021_amd.qp import BatchedBoxQP

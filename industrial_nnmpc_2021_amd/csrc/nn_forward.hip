@@ -17,6 +17,7 @@
 #include <algorithm>
 #include "../../include/nnmpc.h"
 #include "gemm_kernels.h"
+#include "tile_gemm_bf16.h"
 #include "common.h"
 
 using namespace nnmpc;
@@ -24,7 +25,8 @@ using namespace nnmpc;
 namespace {
 
 // rows [0, Bp): pass 1 inputs, rows [Bp, 2Bp): pass 2 inputs; columns padded to ldk.
-__global__ void nn_assemble_k(float* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
+template <class T>
+__global__ void nn_assemble_k(T* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
                               int with_uprev, const double* __restrict__ x,
                               const double* __restrict__ uprev, const double* __restrict__ xs,
                               const double* __restrict__ us, const float* __restrict__ inv_scale) {
@@ -51,7 +53,7 @@ __global__ void nn_assemble_k(float* __restrict__ in, int ldk, int Bp, int B, in
         }
       }
     }
-    in[i] = v;
+    in[i] = (T)v;
   }
 }
 
@@ -78,12 +80,14 @@ struct nnmpc_nn {
   std::vector<int> dims;   // nlayers + 1
   std::vector<int> kpad;   // padded input width of layer l (multiple of 32)
   std::vector<int> npad;   // padded output width of layer l (multiple of 64)
-  std::vector<float*> Wt;  // [npad][kpad] transposed weights
+  std::vector<float*> Wt;  // [npad][kpad] transposed weights (f32 path)
+  std::vector<bf16raw*> Wt16;  // same in bf16 (bf16 path)
+  int use_bf16;
   std::vector<float*> bias;  // [npad]
   int nx, nu, with_uprev, clip, max_batch;
   float* inv_scale;
   double *ulb, *uub;
-  float* act[2];           // ping-pong activations [2*max_batch][maxw]
+  float* act[2];           // ping-pong activations [2*max_batch][maxw] (f32; the bf16 path uses them as bf16 storage, head output f32)
   int maxw;
   double *sx, *suprev, *sxs, *sus, *su;  // staging for host pointers
   hipStream_t stream;
@@ -112,6 +116,13 @@ void launch_layer(hipStream_t s, float* C, size_t ldc, const float* A, size_t ld
   hipLaunchKernelGGL((gemm_nt_f32_k<NB, RELU, BIAS>), grid, dim3(256), TileCfg<NB>::LDS_FLOATS * 4, s,
                      C, ldc, A, lda, Wt, ldb, K, bias);
 }
+template <int NB, bool RELU, bool BIAS, bool OUT16>
+void launch_layer16(hipStream_t s, void* C, size_t ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
+                    size_t ldb, int M, int N, int K, const float* bias) {
+  dim3 grid(N / NB, M / NB);
+  hipLaunchKernelGGL((gemm_nt_bf16_k<NB, RELU, BIAS, OUT16>), grid, dim3(256), TileCfg16<NB>::LDS_BYTES, s,
+                     C, ldc, A, lda, Wt, ldb, K, bias);
+}
 }  // namespace
 
 extern "C" {
@@ -121,7 +132,6 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
                     const double* xscale, const double* ulb, const double* uub, int32_t use_bf16,
                     int32_t max_batch) {
   if (!out || nlayers < 1 || !dims || !W || !b || nx <= 0 || nu <= 0) { set_error("nnmpc_nn_create: bad arguments"); return NNMPC_EINVAL; }
-  if (use_bf16) { set_error("nnmpc_nn_create: bf16 path not built yet"); return NNMPC_ENOTIMPL; }
   const int din = 2 * nx + (with_uprev ? 2 : 1) * nu;
   if (dims[0] != din || dims[nlayers] != nu) { set_error("nnmpc_nn_create: dims[0]=%d (want %d), dims[L]=%d (want %d)", dims[0], din, dims[nlayers], nu); return NNMPC_EINVAL; }
   if ((ulb == nullptr) != (uub == nullptr)) { set_error("nnmpc_nn_create: ulb and uub must both be given or both NULL"); return NNMPC_EINVAL; }
@@ -129,6 +139,7 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("nnmpc_nn_create: no HIP device available (no CPU fallback)"); return NNMPC_EHIP; }
   nnmpc_nn* h = new nnmpc_nn();
   hipGetDevice(&h->device);
+  h->use_bf16 = use_bf16 != 0;
   h->nlayers = nlayers; h->nx = nx; h->nu = nu; h->with_uprev = with_uprev; h->clip = ulb != nullptr;
   h->max_batch = ((std::max(max_batch, 1) + 127) / 128) * 128;
   h->gemm_ms = h->total_ms = 0;
@@ -137,11 +148,13 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   hipEventCreate(&h->e0); hipEventCreate(&h->e1); hipEventCreate(&h->e2); hipEventCreate(&h->e3);
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
+  hipFuncSetAttribute((const void*)gemm_nt_bf16_k<128, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg16<128>::LDS_BYTES);
   h->maxw = 0;
   int rc = 0;
   for (int l = 0; l < nlayers && !rc; ++l) {
-    const int kp = l == 0 ? ((dims[0] + 31) / 32) * 32 : h->npad[l - 1];
-    const int np_ = ((dims[l + 1] + 63) / 64) * 64;
+    const int kp = l == 0 ? ((dims[0] + 63) / 64) * 64 : h->npad[l - 1];
+    // wide layers use 128-wide tiles (pad to 128), narrow ones (the Nu-wide head) 64
+    const int np_ = dims[l + 1] > 64 ? ((dims[l + 1] + 127) / 128) * 128 : 64;
     h->kpad.push_back(kp); h->npad.push_back(np_);
     h->maxw = std::max(h->maxw, std::max(kp, np_));
     std::vector<float> wt((size_t)np_ * kp, 0.f), bb(np_, 0.f);
@@ -157,6 +170,18 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
     hipMemcpy(dw, wt.data(), wt.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(db, bb.data(), bb.size() * 4, hipMemcpyHostToDevice);
     h->Wt.push_back(dw); h->bias.push_back(db);
+    if (h->use_bf16) {
+      std::vector<bf16raw> w16(wt.size());
+      for (size_t e = 0; e < wt.size(); ++e) {   // round to nearest even
+        unsigned u; memcpy(&u, &wt[e], 4);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+        w16[e] = (bf16raw)u;
+      }
+      bf16raw* d16 = nullptr;
+      rc = nn_alloc(h, &d16, w16.size()); if (rc) break;
+      hipMemcpy(d16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice);
+      h->Wt16.push_back(d16);
+    }
   }
   std::vector<float> is(nx, 1.f);
   if (xscale) for (int i = 0; i < nx; ++i) is[i] = (float)(1.0 / xscale[i]);
@@ -211,8 +236,12 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       dx = x + (size_t)b0 * nx; dxs = xs + (size_t)b0 * nx; dus = us + (size_t)b0 * nu;
       dup = h->with_uprev ? uprev + (size_t)b0 * nu : nullptr; du = u + (size_t)b0 * nu;
     }
-    hipLaunchKernelGGL(nn_assemble_k, dim3(2048), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
-                       h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
+    if (h->use_bf16)
+      hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(2048), dim3(256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
+                         h->kpad[0], Bp, nb, nx, nu, h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
+    else
+      hipLaunchKernelGGL(nn_assemble_k<float>, dim3(2048), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
+                         h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     hipEventRecord(h->e2, s);
     int cur = 0;
     const int M = 2 * Bp;
@@ -221,7 +250,16 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       float* C = h->act[cur ^ 1];
       const float* A = h->act[cur];
       const bool last = l == h->nlayers - 1;
-      if (N % 128 == 0) {
+      if (h->use_bf16) {
+        const bf16raw* A16 = reinterpret_cast<const bf16raw*>(A);
+        if (N % 128 == 0) {
+          if (last) launch_layer16<128, false, false, false>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, nullptr);
+          else launch_layer16<128, true, true, true>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, h->bias[l]);
+        } else {
+          if (last) launch_layer16<64, false, false, false>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, nullptr);
+          else launch_layer16<64, true, true, true>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, h->bias[l]);
+        }
+      } else if (N % 128 == 0) {
         if (last) launch_layer<128, false, false>(s, C, N, A, K, h->Wt[l], K, M, N, K, nullptr);
         else launch_layer<128, true, true>(s, C, N, A, K, h->Wt[l], K, M, N, K, h->bias[l]);
       } else {

@@ -209,13 +209,30 @@ class DenseQPRegulator:
             return te - self.tE @ (KA @ x0)
         return te
 
+    def _box_form(self):
+        """(P_box, tq_box) of the box-constrained QP the GPU solves.
+
+        Stable plant: the condensed (P, tq) themselves (G = tE, reference :481).
+        Re-parameterised plant (u = Kx + v, :366-382, G = tE (I + tK tB) =: tE Mg, :479):
+        the inequality rows are box rows of the *input* sequence w = Mg v + tK tA x0 (which is
+        exactly what the reference returns after un-doing the re-parameterisation, :507-509).
+        Mg is unit block-lower-triangular, so substituting v = Mg^-1 (w - tK tA x0) gives a box
+        QP in w with the shared Hessian Mg^-T P Mg^-1 and a linear term that is again linear in
+        x0 -- same optimum, same active rows, no dense-G contraction per sample.
+        """
+        if not self.reparameterize:
+            return self.P, self.tq
+        Mg, KA = condense.constraint_map(self.A, self.B, self.Krep, self.N)
+        Y = scipy.linalg.solve_triangular(Mg, np.eye(Mg.shape[0]), lower=True, unit_diagonal=True)  # Mg^-1
+        Pw = Y.T @ self.P @ Y
+        Pw = 0.5 * (Pw + Pw.T)
+        return Pw, Y.T @ self.tq - Pw @ KA
+
     def _solver(self):
-        if self.reparameterize:
-            raise NotImplementedError(
-                "re-parameterised (unstable-plant) regulator: the dense-G HIP path is not built yet")
         if self._qp is None:
             from .qp import BatchedBoxQP
-            self._qp = BatchedBoxQP(self.P, self.tq, self.Nu, max_batch=self._max_batch, **self._opts)
+            Pb, tqb = self._box_form()
+            self._qp = BatchedBoxQP(Pb, tqb, self.Nu, max_batch=self._max_batch, **self._opts)
         return self._qp
 
     def solve_batch(self, X0, ulb=None, uub=None, first_move_only=False):
