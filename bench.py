@@ -221,8 +221,16 @@ def main():
         # ---- roofline of the dominant kernel (chol_panel_k: MFMA f32), hipEvent-timed in the timed region
         fl, ms = st["panel_flops"], st["panel_ms"]
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM traffic per launch: bytes per algorithmic flop measured with rocprofv3 PMC passes
+        # (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied; profiles/r01_pmc_chol_panel.json)
+        # scaled to this run's flops per launch; null when that profile does not exist.
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_chol_panel.json")
+        if args.workload == "cdu" and os.path.exists(pmc) and st["panel_launches"]:
+            traffic = json.load(open(pmc))["hbm_bytes_per_algorithmic_flop"] * fl / st["panel_launches"]
         out["roofline"] = {"kernel": "chol_panel_k", "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "HBM bytes per launch (PMC-derived, see profiles/r01_pmc_chol_panel.json)",
                            "launches": st["panel_launches"], "avg_launch_ms": ms / max(1, st["panel_launches"]),
                            "time_share": {"chol_panel": ms / st["total_ms"], "chol_diag": st["diag_ms"] / st["total_ms"],
                                           "trsv": st["trsv_ms"] / st["total_ms"]},
