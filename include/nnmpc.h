@@ -61,6 +61,9 @@ typedef struct {
   int32_t max_refine;        /* PCG steps per active set; 0 = 60 */
   int32_t max_rounds;        /* lock-step rounds a problem may stay resident; 0 = 120 */
   int32_t sub_steps;         /* solve sub-steps (PCG steps / KKT check) per round; 0 = 8 */
+  int32_t stale_max_changes; /* polish: reuse the previous factor as PCG preconditioner when at most
+                                this many bounds changed; 0 = 4, < 0 = always refactor */
+  int32_t stale_cg_limit;    /* ... and refactor anyway after this many PCG steps; 0 = 16 */
   float ipm_tol;             /* PDIP exit, objective scaled by 1/median(diag P):
                                 |r_d|_inf and mu <= tol*max(1,|q|_inf); 0 = 1e-2 */
   double refine_tol;         /* PCG exit: |step|_inf <= tol*max(1,|x|_inf); 0 = 1e-10 */

@@ -12,7 +12,8 @@ ST_OPTIMAL, ST_MAXITER, ST_NUMERIC = 0, 1, 2
 class QpOpts(C.Structure):
     _fields_ = [("max_batch", C.c_int32), ("nb", C.c_int32), ("max_ipm_iters", C.c_int32),
                 ("max_polish_rounds", C.c_int32), ("max_refine", C.c_int32),
-                ("max_rounds", C.c_int32), ("sub_steps", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
+                ("max_rounds", C.c_int32), ("sub_steps", C.c_int32), ("stale_max_changes", C.c_int32),
+                ("stale_cg_limit", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
                 ("bound_tol", C.c_double)]
 
 
