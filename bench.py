@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3  # MI355X dense f32 matrix/vector peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s=30.0):
+def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s=30.0, workload="cdu"):
     """Restated reference CPU path (oracle.qp.coneqp_l: cvxopt-style dense-G PDIP,
     fp64, one problem at a time) timed on this host.  Bounded sample."""
     from oracle import qp as oqp
@@ -50,7 +50,9 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s=30.0):
     return {"value": done / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
             "sample": f"{done} problem(s) of the same seeded batch, n={n}, m={2 * n}, dense G, "
                       f"cvxopt-default tolerances, mean {np.mean(its):.1f} PDIP iterations, {dt:.1f} s",
-            "paper_reference": "35 s/solve mean on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"}
+            "paper_reference": ("CVXOPT 35 s/solve mean, 47 s worst on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"
+                                if workload == "cdu" else
+                                "CVXOPT 8-13 s/solve on a 2.4 GHz cluster CPU at the paper's N=450 (n=2700; the code ships N=90, n=540) (KumarRawlingsWright2021 p.7)")}
 
 
 def bench_nn(args, torch, dev, rank, world, dist):
@@ -255,7 +257,7 @@ def main():
             out["parity"] = {"checked": k, "max_rel_err_vs_fp64_oracle": max(errs), "active_set_hamming": ham}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, x0_h, lb_h, ub_h,
-                                               budget_s=20.0 if args.workload == "cdu" else 10.0)
+                                               budget_s=20.0 if args.workload == "cdu" else 10.0, workload=args.workload)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

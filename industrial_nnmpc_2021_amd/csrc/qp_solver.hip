@@ -811,9 +811,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.nb == 0) o.nb = (n <= 1024) ? 64 : 128;
   if (o.nb != 64 && o.nb != 128) { set_error("nb must be 64 or 128"); delete h; return NNMPC_EINVAL; }
   if (o.max_ipm_iters <= 0) o.max_ipm_iters = 40;
-  if (o.max_polish_rounds <= 0) o.max_polish_rounds = 12;
+  if (o.max_polish_rounds <= 0) o.max_polish_rounds = 40;
   if (o.max_refine <= 0) o.max_refine = 60;
-  if (o.max_rounds <= 0) o.max_rounds = 120;
+  if (o.max_rounds <= 0) o.max_rounds = 250;
   if (o.sub_steps <= 0) o.sub_steps = 8;
   if (o.stale_max_changes == 0) o.stale_max_changes = 4;   // < 0 disables factor reuse
   if (o.stale_cg_limit <= 0) o.stale_cg_limit = 16;

@@ -1,0 +1,73 @@
+"""BASELINE.json's full sizes (CDU n = 4480, CSTRs n = 540, batch 10k) through size-independent
+properties: fp64 KKT conditions evaluated independently in numpy, odd symmetry, batch
+permutation invariance / determinism, trivial problems, ragged batch sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, B, seed, sx, **kw):
+    from industrial_nnmpc_2021_amd import synthetic
+    from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    pl = synthetic.plant(name, 0)
+    P, tq, nu = build_regulator_matrices(pl)
+    s = synthetic.samples(pl, B, seed, sx)
+    x0 = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), axis=1)
+    return pl, P, tq, nu, x0, pl["ulb"].T - s["us"], pl["uub"].T - s["us"], BatchedBoxQP(P, tq, nu, **kw)
+
+
+def _kkt(P, tq, nu, N, x0, lb, ub, out, stat_tol):
+    """Independent fp64 check of every returned solution."""
+    Ps = np.tril(P) + np.tril(P, -1).T
+    U = out["u"]
+    G = U @ Ps + x0 @ tq.T                     # gradient rows
+    LB, UB = np.tile(lb, (1, N)), np.tile(ub, (1, N))
+    n = P.shape[0]
+    k, c = np.arange(n) // nu, np.arange(n) % nu
+    au, al = out["active"][:, k * 2 * nu + c], out["active"][:, k * 2 * nu + nu + c]
+    assert not (au & al).any()
+    assert (U <= UB + 1e-9).all() and (U >= LB - 1e-9).all()                 # primal feasibility
+    assert np.abs(np.where(au, U - UB, 0)).max() == 0 and np.abs(np.where(al, U - LB, 0)).max() == 0
+    scale = np.maximum(1.0, np.abs(x0 @ tq.T).max(axis=1, keepdims=True))
+    free = ~(au | al)
+    assert (np.abs(np.where(free, G, 0)) <= stat_tol * scale).all()            # stationarity on the free set
+    assert (np.where(au, -G, 1) > 0).all() and (np.where(al, G, 1) > 0).all()  # multiplier signs
+
+
+def test_cdu_size_kkt_symmetry_permutation():
+    B = 96
+    pl, P, tq, nu, x0, lb, ub, qp = _setup("cdu", B, 21, 2.0, max_batch=128)
+    N = pl["N"]
+    x0[0] = 0.0                                            # trivial problem: u* = 0, nothing active
+    lb[0], ub[0] = -1.0, 1.0
+    out = qp.solve_batch(x0, lb, ub)
+    assert (out["status"] == 0).all()
+    _kkt(P, tq, nu, N, x0, lb, ub, out, 1e-7)
+    assert np.abs(out["u"][0]).max() < 1e-12 and not out["active"][0].any()
+    assert out["active"].any(axis=1).sum() > B // 2          # the batch does exercise the bounds
+    # odd symmetry: (x0, lb, ub) -> (-x0, -ub, -lb)  =>  u -> -u, upper/lower rows swap
+    o2 = qp.solve_batch(-x0, -ub, -lb)
+    assert np.abs(o2["u"] + out["u"]).max() < 1e-8
+    n = P.shape[0]
+    k, c = np.arange(n) // nu, np.arange(n) % nu
+    assert np.array_equal(o2["active"][:, k * 2 * nu + c], out["active"][:, k * 2 * nu + nu + c])
+    # permutation invariance and ragged sizes (continuous batching must not mix problems up)
+    perm = np.random.default_rng(0).permutation(B)[:77]
+    o3 = qp.solve_batch(x0[perm], lb[perm], ub[perm])
+    assert np.abs(o3["u"] - out["u"][perm]).max() < 1e-9
+    assert np.array_equal(o3["active"], out["active"][perm])
+    assert qp.solve_batch(x0[:0], lb[:0], ub[:0])["u"].shape == (0, n)
+
+
+def test_cstrs_config_10k_batch_kkt():
+    """configs[1]: 10k sampled x0 at the CSTRs size (n = 540); more problems than resident slots."""
+    B = 10000
+    pl, P, tq, nu, x0, lb, ub, qp = _setup("cstrs", B, 22, 2.0, max_batch=4096)
+    out = qp.solve_batch(x0, lb, ub)
+    hist = np.bincount(out["status"], minlength=3)
+    assert hist[2] == 0 and hist[0] >= 0.999 * B, hist      # this synthetic plant has cond(P) = 4e7
+    ok = out["status"] == 0
+    sub = {k: v[ok] for k, v in out.items()}
+    _kkt(P, tq, nu, pl["N"], x0[ok], lb[ok], ub[ok], sub, 1e-7)
