@@ -2,8 +2,7 @@
 //   C[M x N] = A[M x K] * B[N x K]'     (row-major, K contiguous in A and B)
 // f32: MFMA 32x32x2 (exact f32), NB x NB tile per 256-thread workgroup, optional
 //      fused epilogue  C = act(C + bias[n]).
-// f64: VALU, 64 x 64 tile (used only for the O(n^2) iterative-refinement
-//      residuals and q = tq x0; <1 % of the flops of a solve).
+// f64: MFMA 16x16x4 f64, 64 x 64 tile (PCG residuals P v and q = tq x0; <1 % of the flops of a solve).
 #pragma once
 #include "tile_gemm.h"
 
@@ -39,50 +38,87 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_k(float* __restrict__ C, size
       }
 }
 
-// M, N multiples of 64, K multiple of 16.  rowphase (nullable): per-row tag, see below.
+// f64 NT GEMM on v_mfma_f64_16x16x4_f64.  M, N multiples of 64, K multiple of 16.
+// 256 threads = 2 x 2 waves, each wave a 32 x 32 block = 2 x 2 MFMA tiles (4 f64 results per
+// lane and tile; f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg).  K-chunks of 16
+// staged through LDS as [64 rows][16 k] with row stride 18 doubles (conflict-free ds_read_b64:
+// lane (i = l & 15, kq = l >> 4) reads k = 4 s + kq of row i).
+// rowphase (nullable): per-row tag; 64-row blocks in which no row has tag `want` are skipped.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 static __global__ __launch_bounds__(256) void gemm_nt_f64_k(double* __restrict__ C, size_t ldc,
                                                      const double* __restrict__ A, size_t lda,
                                                      const double* __restrict__ B, size_t ldb,
                                                      int K, const int* __restrict__ rowphase,
                                                      int want) {
-  __shared__ double As[16][65];
-  __shared__ double Bs[16][65];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  constexpr int LD = 18;
+  __shared__ __attribute__((aligned(16))) double As[2][64 * LD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][64 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  if (rowphase) {  // skip 64-row blocks in which no row (= solver slot) is in phase `want`
+  if (rowphase) {
     const int need = tid < 64 ? (rowphase[m0 + tid] == want) : 0;
     if (!__syncthreads_or(need)) return;
   }
-  double c[4][4];
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[i][j] = 0.0;
-  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // staging: 64 rows x 16 doubles = 512 double2 per operand -> 2 per thread
+  const int lrow0 = tid >> 3, lc = (tid & 7) * 2;           // rows lrow0, lrow0 + 32
+  const double* Ag = A + (size_t)m0 * lda;
+  const double* Bg = B + (size_t)n0 * ldb;
+  f64x2 ra[2], rb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + 256 * i, row = e >> 4, k = e & 15;
-      As[k][row] = A[(size_t)(m0 + row) * lda + k0 + k];
-      Bs[k][row] = B[(size_t)(n0 + row) * ldb + k0 + k];
+  for (int h = 0; h < 2; ++h) {
+    ra[h] = *reinterpret_cast<const f64x2*>(Ag + (size_t)(lrow0 + 32 * h) * lda + lc);
+    rb[h] = *reinterpret_cast<const f64x2*>(Bg + (size_t)(lrow0 + 32 * h) * ldb + lc);
+  }
+  const int li = lane & 15, kq = lane >> 4;
+  const int nk = K / 16;
+  for (int kc = 0; kc < nk; ++kc) {
+    double* sA = As[kc & 1];
+    double* sB = Bs[kc & 1];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<f64x2*>(sA + (lrow0 + 32 * h) * LD + lc) = ra[h];
+      *reinterpret_cast<f64x2*>(sB + (lrow0 + 32 * h) * LD + lc) = rb[h];
     }
     __syncthreads();
+    if (kc + 1 < nk) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      double a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[i][j] += a[i] * b[j];
+      for (int h = 0; h < 2; ++h) {
+        ra[h] = *reinterpret_cast<const f64x2*>(Ag + (size_t)(lrow0 + 32 * h) * lda + (kc + 1) * 16 + lc);
+        rb[h] = *reinterpret_cast<const f64x2*>(Bg + (size_t)(lrow0 + 32 * h) * ldb + (kc + 1) * 16 + lc);
+      }
     }
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = sA[(wr * 32 + t * 16 + li) * LD + 4 * s + kq];
+        b[t] = sB[(wc * 32 + t * 16 + li) * LD + 4 * s + kq];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      C[(size_t)(m0 + ty * 4 + i) * ldc + n0 + tx * 4 + j] = c[i][j];
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int col = n0 + wc * 32 + j * 16 + (lane & 15);
+        C[(size_t)row * ldc + col] = acc[i][j][r];
+      }
 }
 
 }  // namespace nnmpc
