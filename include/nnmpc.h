@@ -81,6 +81,7 @@ typedef struct {
   double trsv_ms;            /* same for trsv */
   double total_ms;           /* hipEvent time of whole solve_batch calls */
   double panel_flops;        /* algorithmic flops executed by chol_panel launches */
+  int64_t trsv_solves;       /* per-problem triangular solve pairs (L y = r, L'x = y) executed */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);

@@ -21,7 +21,7 @@ class QpStats(C.Structure):
     _fields_ = [("problems", C.c_int64), ("rounds", C.c_int64), ("factorizations", C.c_int64),
                 ("ipm_iterations", C.c_int64), ("panel_launches", C.c_int64),
                 ("panel_ms", C.c_double), ("diag_ms", C.c_double), ("trsv_ms", C.c_double),
-                ("total_ms", C.c_double), ("panel_flops", C.c_double)]
+                ("total_ms", C.c_double), ("panel_flops", C.c_double), ("trsv_solves", C.c_int64)]
 
 
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",

@@ -383,6 +383,7 @@ struct TrsvArgs {
   const float* rhs;   // [slots][np]
   float* sol;         // [slots][np]
   const int* flag;    // [slots]
+  unsigned long long* count;  // number of slot-solves executed (statistics)
 };
 
 template <int NB>
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(256) void trsv_k(TrsvArgs a) {
   }
   float* sol = a.sol + (size_t)p * a.np;
   for (int r = tid; r < a.np; r += 256) sol[r] = ys[r];
+  if (tid == 0 && a.count) atomicAdd(a.count, 1ULL);
 }
 
 }  // namespace nnmpc

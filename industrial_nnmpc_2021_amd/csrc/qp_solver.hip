@@ -588,6 +588,7 @@ struct nnmpc_qp {
   float* L;
   float* Y;
   float* Dacc;
+  unsigned long long* trsv_count;
   QpDev d;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
   double* x0_64;        // [seg_max][ka]
@@ -712,7 +713,7 @@ template <int NB>
 void solve_all(nnmpc_qp* h, int nslots, const int* flag) {
   TrsvArgs a;
   a.n = h->n; a.np = h->np; a.T = h->T; a.tiles = h->tiles;
-  a.L = h->L; a.Y = h->Y; a.rhs = h->d.rhs; a.sol = h->d.sol; a.flag = flag;
+  a.L = h->L; a.Y = h->Y; a.rhs = h->d.rhs; a.sol = h->d.sol; a.flag = flag; a.count = h->trsv_count;
   EvScope es(h, 2, 0.0);
   hipLaunchKernelGGL((trsv_k<NB>), dim3(nslots), dim3(256), (h->np + 5 * NB) * 4, h->stream, a);
 }
@@ -843,7 +844,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
 #define A_(ptr, cnt) if (!rc) rc = dev_alloc(h, &(ptr), (size_t)(cnt))
   A_(h->Pt, h->tiles * nb2); A_(h->P32, (size_t)np * np); A_(h->P64, (size_t)np * np);
   A_(h->tq64, (size_t)np * ka); A_(h->Kunc32, (size_t)np * ka); A_(h->pdiag, np);
-  A_(h->L, (size_t)S * h->tiles * nb2); A_(h->Y, (size_t)S * h->T * nb2); A_(h->Dacc, (size_t)S * h->T * nb2);
+  A_(h->L, (size_t)S * h->tiles * nb2); A_(h->Y, (size_t)S * h->T * nb2); A_(h->Dacc, (size_t)S * h->T * nb2); A_(h->trsv_count, 1);
   QpDev& d = h->d;
   const size_t V = (size_t)S * np;
   A_(d.u, V); A_(d.zu, V); A_(d.zl, V); A_(d.lbv, V); A_(d.ubv, V); A_(d.q, V); A_(d.PU, V);
@@ -945,6 +946,12 @@ int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on) {
 int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
   if (!h || !out) return NNMPC_EINVAL;
   *out = h->stats;
+  {
+    unsigned long long c = 0;
+    hipMemcpy(&c, h->trsv_count, sizeof(c), hipMemcpyDeviceToHost);
+    out->trsv_solves = (int64_t)c;
+    if (reset) hipMemset(h->trsv_count, 0, sizeof(c));
+  }
   if (reset) memset(&h->stats, 0, sizeof(h->stats));
   return NNMPC_OK;
 }

@@ -25,3 +25,7 @@ print(st)
 fl = st["factorizations"] * n ** 3 / 3
 print("chol algorithmic TFLOP/s over total:", fl / (st["total_ms"] * 1e-3) / 1e12, " panel-only:", st["panel_flops"] / (st["panel_ms"] * 1e-3) / 1e12,
       "panel share", st["panel_ms"] / st["total_ms"], "diag share", st["diag_ms"] / st["total_ms"], "trsv share", st["trsv_ms"] / st["total_ms"])
+T = (n + nb - 1) // nb if nb else 0
+NBv = nb or (64 if n <= 1024 else 128); T = (n + NBv - 1) // NBv
+bytes_per_solve = 2 * (T * (T + 1) // 2 + T) * NBv * NBv * 4
+print("trsv solves/problem", st["trsv_solves"] / B, "trsv TB/s", st["trsv_solves"] * bytes_per_solve / (st["trsv_ms"] * 1e-3) / 1e12)
