@@ -25,6 +25,7 @@ class QpStats(C.Structure):
 
 
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",
+           "nnmpc_qp_solve_batch_warm",
            "nnmpc_qp_set_profiling", "nnmpc_qp_get_stats", "nnmpc_qp_debug_factor_solve",
            "nnmpc_nn_create", "nnmpc_nn_destroy", "nnmpc_nn_forward", "nnmpc_nn_last_ms"]
 
@@ -54,6 +55,8 @@ def load():
     lib.nnmpc_qp_destroy.argtypes = [vp]
     lib.nnmpc_qp_solve_batch.restype = i32
     lib.nnmpc_qp_solve_batch.argtypes = [vp, i32, dp, dp, dp, dp, dp, dp, dp, i32]
+    lib.nnmpc_qp_solve_batch_warm.restype = i32
+    lib.nnmpc_qp_solve_batch_warm.argtypes = [vp, i32, dp, dp, dp, dp, dp, dp, dp, dp, i32]
     lib.nnmpc_qp_set_profiling.restype = i32
     lib.nnmpc_qp_set_profiling.argtypes = [vp, i32]
     lib.nnmpc_qp_get_stats.restype = i32

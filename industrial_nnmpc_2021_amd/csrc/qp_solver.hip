@@ -51,6 +51,7 @@ struct QpDev {
   // segment-level inputs (problem-indexed) the slots are (re)filled from
   const double *q64_all, *lb_all, *ub_all;   // [seg][np], [seg][nu], [seg][nu]
   const float* uunc_all;                      // [seg][np]
+  const unsigned char* guess_all;             // [seg][n] active-set guess (0 free/1 upper/2 lower) or NULL
   int *slot_prob, *age, *next_prob;
   int seg_count, max_rounds;
   int *phase, *f_factor, *f_solve, *istep, *ipm_it, *nfac, *prounds, *rcnt, *psub, *fail, *stale;
@@ -157,11 +158,26 @@ __global__ __launch_bounds__(256) void refill_k(QpDev d) {
     d.r64[o + r] = 0.0; d.p64[o + r] = 0.0; d.v64[o + r] = 0.0;
   }
   qm = block_max(qm, shf);
+  const bool warm = d.guess_all != nullptr;
+  if (warm) {
+    // caller-supplied active set (e.g. the shifted set of the previous step of a closed-loop
+    // chain): skip the PDIP, start the polish on it; the fp64 KKT check still certifies the result
+    for (int r = tid; r < d.n; r += 256) {
+      const int c = r % d.nu;
+      int s = d.guess_all[(size_t)idx * d.n + r];
+      if (s > 2) s = 0;
+      const double xv = s == 1 ? d.ub_all[(size_t)idx * d.nu + c]
+                      : s == 2 ? d.lb_all[(size_t)idx * d.nu + c] : (double)d.u[o + r];
+      d.st[o + r] = (unsigned char)s;
+      d.x[o + r] = xv;
+      d.v64[o + r] = xv;
+    }
+  }
   if (tid == 0) {
     d.slot_prob[p] = idx;
     d.age[p] = 0;
     d.qscale[p] = fmaxf(1.f, qm);
-    d.phase[p] = PH_INIT;
+    d.phase[p] = warm ? PH_POLISH : PH_INIT;
     d.f_factor[p] = d.f_solve[p] = 0;
     d.ipm_it[p] = d.nfac[p] = d.prounds[p] = d.rcnt[p] = d.psub[p] = d.fail[p] = d.stale[p] = 0;
     d.mu[p] = d.gap[p] = d.smu[p] = 0.f; d.rz[p] = 0.0;
@@ -730,7 +746,7 @@ void solve_dispatch(nnmpc_qp* h, int nslots, const int* flag) {
 // segment by two GEMMs, then lock-step rounds over the resident slots with
 // finished slots refilled from the segment until it is exhausted.
 int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_dev, const double* ub_dev,
-                  double* u_dev, uint32_t* act_dev, int32_t* st_dev, int32_t* it_dev) {
+                  const unsigned char* guess_dev, double* u_dev, uint32_t* act_dev, int32_t* st_dev, int32_t* it_dev) {
   QpDev& d = h->d;
   hipStream_t s = h->stream;
   const int rows = h->slots;
@@ -741,11 +757,12 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
   else HIPCHK(hipMemsetAsync(h->uunc_all, 0, (size_t)segp * h->np * sizeof(float), s));
   d.q64_all = h->q64_all; d.uunc_all = h->uunc_all; d.lb_all = lb_dev; d.ub_all = ub_dev;
   d.seg_count = nprob;
+  d.guess_all = guess_dev;
   d.u_out = u_dev; d.act_out = act_dev; d.status_out = st_dev; d.iters_out = it_dev;
   hipLaunchKernelGGL(reset_slots_k, dim3((rows + 255) / 256), dim3(256), 0, s, d);
 
   int cnt[8];
-  bool any_ipm = true, any_polish = false;
+  bool any_ipm = true, any_polish = guess_dev != nullptr;
   int issued = 0;  // problems handed to slots so far (host mirror of *next_prob, upper bound)
   const int hard_cap = 1000000;
   for (int round = 0; round < hard_cap; ++round) {
@@ -753,6 +770,7 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
     if (issued < nprob) {
       hipLaunchKernelGGL(refill_k, dim3(rows), dim3(256), 0, s, d);
       any_ipm = true;
+      if (guess_dev) any_polish = true;
     }
     if (any_ipm) gemm32(h, d.PU, h->np, d.u, h->np, h->P32, h->np, rows, h->np, h->np);
     if (any_polish) gemm64(h, d.PX, h->np, d.v64, h->np, h->P64, h->np, rows, h->np, h->np, d.phase, PH_POLISH);
@@ -958,6 +976,12 @@ int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
 
 int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double* lb, const double* ub,
                          double* u, uint32_t* active, int32_t* status, int32_t* iters, int32_t ptr_kind) {
+  return nnmpc_qp_solve_batch_warm(h, B, x0, lb, ub, nullptr, u, active, status, iters, ptr_kind);
+}
+
+int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const double* lb, const double* ub,
+                              const uint8_t* guess, double* u, uint32_t* active, int32_t* status,
+                              int32_t* iters, int32_t ptr_kind) {
   if (!h || B < 0 || !x0 || !lb || !ub || !u) { set_error("nnmpc_qp_solve_batch: bad arguments"); return NNMPC_EINVAL; }
   if (B == 0) return NNMPC_OK;
   HIPCHK(hipSetDevice(h->device));
@@ -966,19 +990,23 @@ int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double*
   if (h->profiling) { e_tot0 = ev_get(h); hipEventRecord(h->ev_pool[e_tot0], h->stream); }
   // device scratch for outputs when the caller hands host pointers
   double* u_stage = nullptr; uint32_t* a_stage = nullptr; int32_t* s_stage = nullptr; int32_t* i_stage = nullptr;
+  unsigned char* g_stage = nullptr;
   const int gmax = std::min(G, (int)B);
   if (ptr_kind == NNMPC_HOST) {
     HIPCHK(hipMalloc((void**)&u_stage, (size_t)gmax * h->n * sizeof(double)));
     HIPCHK(hipMalloc((void**)&a_stage, (size_t)gmax * h->words * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void**)&s_stage, (size_t)gmax * sizeof(int32_t)));
     HIPCHK(hipMalloc((void**)&i_stage, (size_t)gmax * 2 * sizeof(int32_t)));
+    if (guess) HIPCHK(hipMalloc((void**)&g_stage, (size_t)gmax * h->n));
   }
   int rc = 0;
   for (int b0 = 0; b0 < B && !rc; b0 += G) {
     const int nb = std::min(G, B - b0);
     const double *x0d, *lbd, *ubd;
     double* ud; uint32_t* ad; int32_t* sd; int32_t* idv;
+    const unsigned char* gd = nullptr;
     if (ptr_kind == NNMPC_HOST) {
+      if (guess) { HIPCHK(hipMemcpyAsync(g_stage, guess + (size_t)b0 * h->n, (size_t)nb * h->n, hipMemcpyHostToDevice, h->stream)); gd = g_stage; }
       HIPCHK(hipMemcpyAsync(h->in_stage, x0 + (size_t)b0 * h->n_aug, (size_t)nb * h->n_aug * 8, hipMemcpyHostToDevice, h->stream));
       HIPCHK(hipMemcpyAsync(h->lb_d, lb + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
       HIPCHK(hipMemcpyAsync(h->ub_d, ub + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
@@ -986,12 +1014,13 @@ int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double*
       ud = u_stage; ad = active ? a_stage : nullptr; sd = status ? s_stage : nullptr; idv = iters ? i_stage : nullptr;
     } else {
       x0d = x0 + (size_t)b0 * h->n_aug; lbd = lb + (size_t)b0 * h->nu; ubd = ub + (size_t)b0 * h->nu;
+      if (guess) gd = guess + (size_t)b0 * h->n;
       ud = u + (size_t)b0 * h->n;
       ad = active ? active + (size_t)b0 * h->words : nullptr;
       sd = status ? status + b0 : nullptr;
       idv = iters ? iters + 2 * (size_t)b0 : nullptr;
     }
-    rc = solve_segment(h, nb, x0d, lbd, ubd, ud, ad, sd, idv);
+    rc = solve_segment(h, nb, x0d, lbd, ubd, gd, ud, ad, sd, idv);
     if (!rc && ptr_kind == NNMPC_HOST) {
       HIPCHK(hipMemcpy(u + (size_t)b0 * h->n, u_stage, (size_t)nb * h->n * 8, hipMemcpyDeviceToHost));
       if (active) HIPCHK(hipMemcpy(active + (size_t)b0 * h->words, a_stage, (size_t)nb * h->words * 4, hipMemcpyDeviceToHost));
@@ -1003,6 +1032,7 @@ int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double*
   if (a_stage) hipFree(a_stage);
   if (s_stage) hipFree(s_stage);
   if (i_stage) hipFree(i_stage);
+  if (g_stage) hipFree(g_stage);
   if (h->profiling) {
     size_t e1 = ev_get(h);
     hipEventRecord(h->ev_pool[e1], h->stream);

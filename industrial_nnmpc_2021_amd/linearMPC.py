@@ -235,17 +235,18 @@ class DenseQPRegulator:
             self._qp = BatchedBoxQP(Pb, tqb, self.Nu, max_batch=self._max_batch, **self._opts)
         return self._qp
 
-    def solve_batch(self, X0, ulb=None, uub=None, first_move_only=False):
+    def solve_batch(self, X0, ulb=None, uub=None, first_move_only=False, guess=None):
         """B problems at once.  X0 (B, n_aug); ulb/uub (B, Nu) or (Nu,[1]) (default: self.ulb/uub).
 
         Returns (U (B, N*Nu) or (B, Nu), info) with info = dict(active (B, 2 N Nu) bool in the
-        row order of G, status (B,), ipm_iters, factorizations).
+        row order of G, status (B,), ipm_iters, factorizations).  ``guess`` (B, N*Nu) uint8
+        (0 free / 1 upper / 2 lower) warm-starts the solver on an estimated active set.
         """
         lb = self.ulb if ulb is None else ulb
         ub = self.uub if uub is None else uub
         out = self._solver().solve_batch(np.asarray(X0, float).reshape(-1, self.Nx),
                                          np.asarray(lb, float).reshape(-1, self.Nu),
-                                         np.asarray(ub, float).reshape(-1, self.Nu))
+                                         np.asarray(ub, float).reshape(-1, self.Nu), guess=guess)
         U = out.pop("u")
         self.last_info = out
         return (U[:, :self.Nu] if first_move_only else U), out
@@ -345,11 +346,11 @@ class LinearMPCController:
         return regulator.solve(x0) + np.tile(us, (regulator.N, 1))
 
     @staticmethod
-    def get_control_sequence_batch(regulator, X, Uprev, Xs, Us, ulb, uub, first_move_only=True):
+    def get_control_sequence_batch(regulator, X, Uprev, Xs, Us, ulb, uub, first_move_only=True, guess=None):
         """Batched counterpart of get_control_sequence: rows are samples (B, .)."""
         X0 = np.concatenate((X - Xs, Uprev - Us), axis=1)
         U, info = regulator.solve_batch(X0, ulb.reshape(1, -1) - Us, uub.reshape(1, -1) - Us,
-                                        first_move_only=first_move_only)
+                                        first_move_only=first_move_only, guess=guess)
         return U + (Us if first_move_only else np.tile(Us, (1, regulator.N))), info
 
     @staticmethod
@@ -389,12 +390,15 @@ def _save_training_data(dictionary, filename):
         return filename + ".npz"
 
 
-def simulate_chains(x0, uprev0, A, B, Bd, regulator, ulb, uub, target_selectors, setpoints, disturbances):
+def simulate_chains(x0, uprev0, A, B, Bd, regulator, ulb, uub, target_selectors, setpoints, disturbances,
+                    warm_start=True):
     """Lock-step closed-loop chains: chain c follows setpoints[c] (T, Ny), disturbances[c] (T, Nd).
 
     Per step: target pair per chain (host), ONE batched regulator solve for all chains (GPU),
     model step x+ = A x + B u + Bd d.  Same recurrences and outputs as the reference's
-    simulate_offline (:845-872), which runs one chain per OS process.
+    simulate_offline (:845-872), which runs one chain per OS process.  With ``warm_start`` the
+    active set of step t, shifted by one stage, seeds the solve of step t+1 (consecutive QPs of a
+    chain differ little); results are identical either way (every solve is KKT-certified).
     """
     nc = len(setpoints)
     T = setpoints[0].shape[0]
@@ -404,19 +408,26 @@ def simulate_chains(x0, uprev0, A, B, Bd, regulator, ulb, uub, target_selectors,
     out = dict(x=np.empty((nc, T, Nx)), uprev=np.empty((nc, T, Nu)), xs=np.empty((nc, T, Nx)),
                us=np.empty((nc, T, Nu)), u=np.empty((nc, T, Nu)))
     status = np.zeros((nc, T), np.int32)
+    nfac = np.zeros((nc, T), np.int32)
+    guess = None
     for t in range(T):
         Xs, Us = np.empty((nc, Nx)), np.empty((nc, Nu))
         for c in range(nc):
             (xs, us) = LinearMPCController.get_target_pair(target_selectors[c], setpoints[c][t][:, None],
                                                            disturbances[c][t][:, None])
             Xs[c], Us[c] = xs[:, 0], us[:, 0]
-        U, info = LinearMPCController.get_control_sequence_batch(regulator, X, Uprev, Xs, Us, ulb, uub)
+        U, info = LinearMPCController.get_control_sequence_batch(regulator, X, Uprev, Xs, Us, ulb, uub, guess=guess)
         status[:, t] = info["status"]
+        nfac[:, t] = info["factorizations"]
+        if warm_start:
+            st = regulator._solver().active_to_state(info["active"])      # (nc, N*Nu)
+            guess = np.concatenate((st[:, Nu:], st[:, -Nu:]), axis=1)      # shift one stage, repeat the last
         out["x"][:, t], out["uprev"][:, t], out["xs"][:, t], out["us"][:, t], out["u"][:, t] = X, Uprev, Xs, Us, U
         D = np.stack([disturbances[c][t] for c in range(nc)])
         X = X @ A.T + U @ B.T + D @ Bd.T
         Uprev = U
     out["status"] = status
+    out["factorizations"] = nfac
     return out
 
 

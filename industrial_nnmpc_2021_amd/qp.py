@@ -65,8 +65,9 @@ class BatchedBoxQP:
 
     __del__ = close
 
-    def solve_batch(self, x0, lb, ub):
-        """numpy in / numpy out.  x0 (B, n_aug), lb/ub (B, nu) or (nu,).
+    def solve_batch(self, x0, lb, ub, guess=None):
+        """numpy in / numpy out.  x0 (B, n_aug), lb/ub (B, nu) or (nu,); guess: optional (B, n) uint8
+        active-set estimate (0 free, 1 upper, 2 lower) that replaces the PDIP phase (warm start).
 
         Returns dict(u (B, n), active (B, 2n) bool in the row order of the
         reference's G, status (B,), ipm_iters (B,), factorizations (B,)).
@@ -79,11 +80,22 @@ class BatchedBoxQP:
         act = np.zeros((B, self.words), np.uint32)
         status = np.empty(B, np.int32)
         iters = np.empty((B, 2), np.int32)
-        _lib.check(self._lib.nnmpc_qp_solve_batch(
-            self._h, B, *(a.ctypes.data_as(C.c_void_p) for a in (x0, lb, ub, u, act, status, iters)),
-            _lib.HOST), "nnmpc_qp_solve_batch")
+        gp = None
+        if guess is not None:
+            guess = np.ascontiguousarray(guess, dtype=np.uint8).reshape(B, self.n)
+            gp = guess.ctypes.data_as(C.c_void_p)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.nnmpc_qp_solve_batch_warm(
+            self._h, B, p(x0), p(lb), p(ub), gp, p(u), p(act), p(status), p(iters), _lib.HOST),
+            "nnmpc_qp_solve_batch")
         bits = np.unpackbits(act.view(np.uint8), axis=1, bitorder="little")[:, :2 * self.n].astype(bool)
         return dict(u=u, active=bits, status=status, ipm_iters=iters[:, 0], factorizations=iters[:, 1])
+
+    def active_to_state(self, active):
+        """(B, 2n) bool rows of G -> (B, n) uint8 per-variable state (the `guess` format)."""
+        n, nu = self.n, self.nu
+        k, c = np.arange(n) // nu, np.arange(n) % nu
+        return (active[:, k * 2 * nu + c].astype(np.uint8) + 2 * active[:, k * 2 * nu + nu + c].astype(np.uint8))
 
     def solve_batch_device(self, B, x0, lb, ub, u, active=None, status=None, iters=None):
         """HBM-resident buffers (objects with data_ptr(), e.g. torch CUDA tensors, f64/u32/i32)."""
