@@ -64,6 +64,10 @@ typedef struct {
   int32_t stale_max_changes; /* polish: reuse the previous factor as PCG preconditioner when at most
                                 this many bounds changed; 0 = 4, < 0 = always refactor */
   int32_t stale_cg_limit;    /* ... and refactor anyway after this many PCG steps; 0 = 16 */
+  int32_t method;            /* 0 = auto: shared-inverse active-set pass (needs nnmpc_qp_set_inverse),
+                                PDIP for what it leaves; 1 = PDIP only; 2 = active-set pass only */
+  int32_t asm_max_active;    /* active-set pass: largest active set handled (<= 768); 0 = 768 */
+  int32_t asm_max_rounds;    /* ... and its round budget; 0 = 40 */
   float ipm_tol;             /* PDIP exit, objective scaled by 1/median(diag P):
                                 |r_d|_inf and mu <= tol*max(1,|q|_inf); 0 = 1e-2 */
   double refine_tol;         /* PCG exit: |step|_inf <= tol*max(1,|x|_inf); 0 = 1e-10 */
@@ -82,6 +86,8 @@ typedef struct {
   double total_ms;           /* hipEvent time of whole solve_batch calls */
   double panel_flops;        /* algorithmic flops executed by chol_panel launches */
   int64_t trsv_solves;       /* per-problem triangular solve pairs (L y = r, L'x = y) executed */
+  int64_t asm_solved;        /* problems finished (and certified) by the active-set pass */
+  int64_t asm_rounds;        /* lock-step rounds of the active-set pass */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);
@@ -108,6 +114,13 @@ int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double*
 int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const double* lb,
                               const double* ub, const uint8_t* guess, double* u, uint32_t* active,
                               int32_t* status, int32_t* iters, int32_t ptr_kind);
+
+/* Enables the shared-inverse active-set pass: Hinv = P^-1 (n x n, fp64), Kunc = -Hinv tq (n x n_aug).
+ * All samples share P (reference lib/linearMPC.py:472), so on an active set A the equality-constrained
+ * optimum is x = x_unc - Hinv[:,A] lam with lam = (Hinv_AA)^-1 (x_unc,A - b_A): a primal-dual active-set
+ * iteration needs no n^3 factorisation.  Results are certified against P in fp64; problems the pass
+ * cannot finish go through the PDIP path. */
+int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc);
 
 int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on);
 int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset);

@@ -13,7 +13,8 @@ class QpOpts(C.Structure):
     _fields_ = [("max_batch", C.c_int32), ("nb", C.c_int32), ("max_ipm_iters", C.c_int32),
                 ("max_polish_rounds", C.c_int32), ("max_refine", C.c_int32),
                 ("max_rounds", C.c_int32), ("sub_steps", C.c_int32), ("stale_max_changes", C.c_int32),
-                ("stale_cg_limit", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
+                ("stale_cg_limit", C.c_int32), ("method", C.c_int32), ("asm_max_active", C.c_int32),
+                ("asm_max_rounds", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
                 ("bound_tol", C.c_double)]
 
 
@@ -21,11 +22,12 @@ class QpStats(C.Structure):
     _fields_ = [("problems", C.c_int64), ("rounds", C.c_int64), ("factorizations", C.c_int64),
                 ("ipm_iterations", C.c_int64), ("panel_launches", C.c_int64),
                 ("panel_ms", C.c_double), ("diag_ms", C.c_double), ("trsv_ms", C.c_double),
-                ("total_ms", C.c_double), ("panel_flops", C.c_double), ("trsv_solves", C.c_int64)]
+                ("total_ms", C.c_double), ("panel_flops", C.c_double), ("trsv_solves", C.c_int64), ("asm_solved", C.c_int64),
+                ("asm_rounds", C.c_int64)]
 
 
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",
-           "nnmpc_qp_solve_batch_warm",
+           "nnmpc_qp_solve_batch_warm", "nnmpc_qp_set_inverse",
            "nnmpc_qp_set_profiling", "nnmpc_qp_get_stats", "nnmpc_qp_debug_factor_solve",
            "nnmpc_nn_create", "nnmpc_nn_destroy", "nnmpc_nn_forward", "nnmpc_nn_last_ms"]
 
@@ -57,6 +59,8 @@ def load():
     lib.nnmpc_qp_solve_batch.argtypes = [vp, i32, dp, dp, dp, dp, dp, dp, dp, i32]
     lib.nnmpc_qp_solve_batch_warm.restype = i32
     lib.nnmpc_qp_solve_batch_warm.argtypes = [vp, i32, dp, dp, dp, dp, dp, dp, dp, dp, i32]
+    lib.nnmpc_qp_set_inverse.restype = i32
+    lib.nnmpc_qp_set_inverse.argtypes = [vp, dp, dp]
     lib.nnmpc_qp_set_profiling.restype = i32
     lib.nnmpc_qp_set_profiling.argtypes = [vp, i32]
     lib.nnmpc_qp_get_stats.restype = i32

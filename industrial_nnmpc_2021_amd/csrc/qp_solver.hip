@@ -26,6 +26,7 @@
 #include "../../include/nnmpc.h"
 #include "chol_kernels.h"
 #include "gemm_kernels.h"
+#include "qp_asm.h"
 #include "common.h"
 
 using namespace nnmpc;
@@ -606,6 +607,14 @@ struct nnmpc_qp {
   float* Dacc;
   unsigned long long* trsv_count;
   QpDev d;
+  // shared-inverse active-set path (qp_asm.h)
+  bool have_inverse;
+  double* H64;      // np x np
+  double* Kunc64;   // np x ka
+  double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch;
+  unsigned char* asm_st;
+  int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status;
+  int asm_pool;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
   double* x0_64;        // [seg_max][ka]
   float* x0_32;
@@ -805,6 +814,88 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
   return 0;
 }
 
+// Shared-inverse active-set pass over one segment; problems it cannot finish are marked 3 in
+// h->asm_status and re-solved by the PDIP path (solve_segment) on a compacted copy.
+int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_dev, const double* ub_dev,
+                      const unsigned char* guess_dev, double* u_dev, uint32_t* act_dev, int32_t* st_dev, int32_t* it_dev) {
+  hipStream_t s = h->stream;
+  const int segp = ((nprob + 127) / 128) * 128;
+  hipLaunchKernelGGL(pad_x0_k, dim3(512), dim3(256), 0, s, h->x0_64, h->x0_32, x0_dev, nprob, h->n_aug, h->ka, segp);
+  gemm64(h, h->q64_all, h->np, h->x0_64, h->ka, h->tq64, h->ka, segp, h->np, h->ka);
+  gemm64(h, h->asm_xunc, h->np, h->x0_64, h->ka, h->Kunc64, h->ka, segp, h->np, h->ka);
+  AsmDev a;
+  a.n = h->n; a.np = h->np; a.nu = h->nu; a.nseg = nprob;
+  a.max_active = h->opts.asm_max_active; a.max_rounds = h->opts.asm_max_rounds;
+  a.bound_tol = h->opts.bound_tol; a.stat_tol = 1e-8; a.pscale_unused = 0.0;
+  a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
+  a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
+  a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
+  a.biglist = h->asm_biglist; a.scratch = h->asm_scratch;
+  a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
+  hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
+  const int lds_small = ((a.max_active + 1) / 2 + a.max_active + ASM_MLDS * (ASM_MLDS + 1) / 2) * 8;
+  const int lds_big = ((a.max_active + 1) / 2 + a.max_active) * 8;
+  int cnt[2] = {0, 0};
+  int rounds = 0;
+  for (; rounds < a.max_rounds + 1; ++rounds) {
+    HIPCHK(hipMemsetAsync(h->asm_counters, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL((asm_lambda_k<0>), dim3(nprob), dim3(256), lds_small, s, a);
+    hipLaunchKernelGGL((asm_lambda_k<1>), dim3(h->asm_pool), dim3(256), lds_big, s, a);
+    gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, segp, h->np, h->np, h->asm_state, ASM_RUN);
+    hipLaunchKernelGGL(asm_update_k, dim3(nprob), dim3(256), 0, s, a);
+    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->stats.asm_rounds += 1;
+    if (cnt[0] == 0) break;
+  }
+  // certification with P itself: px = x P (only finished rows matter)
+  gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);
+  hipLaunchKernelGGL(asm_certify_k, dim3(nprob), dim3(256), 0, s, a, h->pscale);
+  std::vector<int> st(nprob);
+  HIPCHK(hipMemcpyAsync(st.data(), h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  std::vector<int> fb;
+  for (int p = 0; p < nprob; ++p) if (st[p] != 0) fb.push_back(p);
+  h->stats.asm_solved += nprob - (int64_t)fb.size();
+  if (st_dev) HIPCHK(hipMemcpyAsync(st_dev, h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (fb.empty()) { h->stats.problems += nprob; return 0; }
+  if (h->opts.method == 2) {                           // asm only: report the rest as not certified
+    for (int& v : st) v = v ? NNMPC_ST_MAXITER : 0;
+    if (st_dev) HIPCHK(hipMemcpy(st_dev, st.data(), (size_t)nprob * sizeof(int), hipMemcpyHostToDevice));
+    h->stats.problems += nprob;
+    return 0;
+  }
+  // ---- PDIP fallback on the compacted remainder
+  const int cntf = (int)fb.size();
+  int* list = nullptr; double *x0c = nullptr, *lbc = nullptr, *ubc = nullptr, *uc = nullptr;
+  uint32_t* actc = nullptr; int *stc = nullptr, *itc = nullptr;
+  HIPCHK(hipMalloc((void**)&list, cntf * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&x0c, (size_t)cntf * h->n_aug * 8));
+  HIPCHK(hipMalloc((void**)&lbc, (size_t)cntf * h->nu * 8));
+  HIPCHK(hipMalloc((void**)&ubc, (size_t)cntf * h->nu * 8));
+  HIPCHK(hipMalloc((void**)&uc, (size_t)cntf * h->n * 8));
+  HIPCHK(hipMalloc((void**)&actc, (size_t)cntf * h->words * 4));
+  HIPCHK(hipMalloc((void**)&stc, (size_t)cntf * 4));
+  HIPCHK(hipMalloc((void**)&itc, (size_t)cntf * 8));
+  HIPCHK(hipMemcpy(list, fb.data(), cntf * sizeof(int), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(asm_gather_k, dim3(cntf), dim3(128), 0, s, x0c, lbc, ubc, x0_dev, lb_dev, ub_dev, list, cntf, h->n_aug, h->nu);
+  int rc = 0;
+  for (int b0 = 0; b0 < cntf && !rc; b0 += h->seg_max) {
+    const int nb = std::min(h->seg_max, cntf - b0);
+    rc = solve_segment(h, nb, x0c + (size_t)b0 * h->n_aug, lbc + (size_t)b0 * h->nu, ubc + (size_t)b0 * h->nu, nullptr,
+                       uc + (size_t)b0 * h->n, actc + (size_t)b0 * h->words, stc + b0, itc + 2 * (size_t)b0);
+  }
+  if (!rc) {
+    hipLaunchKernelGGL(asm_scatter_k, dim3(cntf), dim3(128), 0, s, u_dev, act_dev, st_dev, it_dev, uc, actc, stc, itc,
+                       list, cntf, h->n, h->words);
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  hipFree(list); hipFree(x0c); hipFree(lbc); hipFree(ubc); hipFree(uc); hipFree(actc); hipFree(stc); hipFree(itc);
+  h->stats.problems += nprob - cntf;   // solve_segment counted the fallback ones
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -823,7 +914,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   nnmpc_qp* h = new nnmpc_qp();
   memset(&h->stats, 0, sizeof(h->stats));
   memset(&h->d, 0, sizeof(h->d));
-  h->profiling = false; h->ev_used = 0;
+  h->profiling = false; h->ev_used = 0; h->have_inverse = false;
   if (opts) h->opts = *opts; else memset(&h->opts, 0, sizeof(h->opts));
   nnmpc_qp_opts& o = h->opts;
   if (o.max_batch <= 0) o.max_batch = 1024;
@@ -836,6 +927,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.sub_steps <= 0) o.sub_steps = 8;
   if (o.stale_max_changes == 0) o.stale_max_changes = 4;   // < 0 disables factor reuse
   if (o.stale_cg_limit <= 0) o.stale_cg_limit = 16;
+  if (o.asm_max_active <= 0) o.asm_max_active = 768;
+  if (o.asm_max_active > 768) o.asm_max_active = 768;
+  if (o.asm_max_rounds <= 0) o.asm_max_rounds = 40;
   if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
   if (o.refine_tol <= 0.0) o.refine_tol = 1e-10;
@@ -873,7 +967,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
   {
     // segment size: as many problems as ~1.5 GB of (q f64 + warm start f32) rows allow
-    long long cap = (long long)(1.5e9 / (12.0 * np));
+    long long cap = (long long)(3.0e9 / (12.0 * np + 32.0 * np + n));
     cap = std::max<long long>(cap, S);
     cap = std::min<long long>(cap, 1 << 20);
     h->seg_max = (int)((cap / 128) * 128);
@@ -885,6 +979,12 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->in_stage, G * n_aug);
   A_(d.lb64, (size_t)S * nu); A_(d.ub64, (size_t)S * nu);
   A_(d.slot_prob, S); A_(d.age, S); A_(d.next_prob, 1);
+  h->asm_pool = 256;
+  A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka);
+  A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
+  A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, 2);
+  A_(h->asm_biglist, G); A_(h->asm_status, G);
+  A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)o.asm_max_active * (o.asm_max_active + 1) / 2));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
   d.n = n; d.np = np; d.nu = nu; d.slots = S; d.words = h->words;
@@ -955,6 +1055,23 @@ int nnmpc_qp_destroy(nnmpc_qp* h) {
   return NNMPC_OK;
 }
 
+int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
+  if (!h || !Hinv || !Kunc) { set_error("nnmpc_qp_set_inverse: bad arguments"); return NNMPC_EINVAL; }
+  HIPCHK(hipSetDevice(h->device));
+  const int n = h->n, np = h->np, ka = h->ka, n_aug = h->n_aug;
+  std::vector<double> hh((size_t)np * np, 0.0), kk((size_t)np * ka, 0.0);
+  for (int r = 0; r < n; ++r) {
+    for (int c = 0; c < n; ++c) hh[(size_t)r * np + c] = 0.5 * (Hinv[(size_t)r * n + c] + Hinv[(size_t)c * n + r]);
+    for (int k = 0; k < n_aug; ++k) kk[(size_t)r * ka + k] = Kunc[(size_t)r * n_aug + k];
+  }
+  HIPCHK(hipMemcpy(h->H64, hh.data(), hh.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
+  const int lds_small = ((h->opts.asm_max_active + 1) / 2 + h->opts.asm_max_active + ASM_MLDS * (ASM_MLDS + 1) / 2) * 8;
+  HIPCHK(hipFuncSetAttribute((const void*)asm_lambda_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+  h->have_inverse = true;
+  return NNMPC_OK;
+}
+
 int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on) {
   if (!h) return NNMPC_EINVAL;
   h->profiling = on != 0;
@@ -1020,7 +1137,8 @@ int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const do
       sd = status ? status + b0 : nullptr;
       idv = iters ? iters + 2 * (size_t)b0 : nullptr;
     }
-    rc = solve_segment(h, nb, x0d, lbd, ubd, gd, ud, ad, sd, idv);
+    if (h->have_inverse && h->opts.method != 1) rc = solve_segment_asm(h, nb, x0d, lbd, ubd, gd, ud, ad, sd, idv);
+    else rc = solve_segment(h, nb, x0d, lbd, ubd, gd, ud, ad, sd, idv);
     if (!rc && ptr_kind == NNMPC_HOST) {
       HIPCHK(hipMemcpy(u + (size_t)b0 * h->n, u_stage, (size_t)nb * h->n * 8, hipMemcpyDeviceToHost));
       if (active) HIPCHK(hipMemcpy(active + (size_t)b0 * h->words, a_stage, (size_t)nb * h->words * 4, hipMemcpyDeviceToHost));

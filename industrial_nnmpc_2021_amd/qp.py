@@ -29,20 +29,29 @@ class BatchedBoxQP:
     stage and tiled along the horizon like the reference's _get_h).
     """
 
-    def __init__(self, P, tq, nu, *, Kunc="auto", max_batch=1024, nb=0, ipm_tol=0.0,
-                 max_rounds=0, max_ipm_iters=0, max_polish_rounds=0, max_refine=0, sub_steps=0, stale_max_changes=0, stale_cg_limit=0):
+    def __init__(self, P, tq, nu, *, Kunc="auto", method="auto", max_batch=1024, nb=0, ipm_tol=0.0,
+                 max_rounds=0, max_ipm_iters=0, max_polish_rounds=0, max_refine=0, sub_steps=0, stale_max_changes=0, stale_cg_limit=0, asm_max_active=0,
+                 asm_max_rounds=0):
         lib = _lib.load()
         P = np.ascontiguousarray(P, dtype=np.float64)
         tq = np.ascontiguousarray(tq, dtype=np.float64)
         n, n_aug = tq.shape
         if P.shape != (n, n) or n % nu:
             raise ValueError("P must be (n, n), tq (n, n_aug), n a multiple of nu")
+        meth = {"auto": 0, "pdip": 1, "asm": 2}[method]
+        Hinv = None
         if isinstance(Kunc, str) and Kunc == "auto":
-            # warm-start gain u_unc = -P^-1 tq x0 (one-time host setup, like the
-            # reference's DARE/condensing in DenseQPRegulator.__init__)
+            # one-time host setup in fp64 (like the reference's DARE/condensing in
+            # DenseQPRegulator.__init__): u_unc = Kunc x0 = -P^-1 tq x0 (warm start), and, for
+            # the shared-inverse active-set pass, P^-1 itself
             import scipy.linalg as sla
             Ps = np.tril(P) + np.tril(P, -1).T
-            Kunc = -sla.cho_solve(sla.cho_factor(Ps, lower=True), tq)
+            cf = sla.cho_factor(Ps, lower=True)
+            Kunc = -sla.cho_solve(cf, tq)
+            if meth != 1:
+                Hinv = sla.cho_solve(cf, np.eye(n))
+        elif meth == 2:
+            raise ValueError("method='asm' needs Kunc='auto' (the inverse Hessian is built with it)")
         if Kunc is not None:
             Kunc = np.ascontiguousarray(Kunc, dtype=np.float64)
         self.n, self.n_aug, self.nu = n, n_aug, nu
@@ -50,13 +59,18 @@ class BatchedBoxQP:
         opts = _lib.QpOpts(max_batch=max_batch, nb=nb, max_ipm_iters=max_ipm_iters,
                            max_polish_rounds=max_polish_rounds, max_refine=max_refine,
                            max_rounds=max_rounds, sub_steps=sub_steps, stale_max_changes=stale_max_changes,
-                           stale_cg_limit=stale_cg_limit, ipm_tol=ipm_tol, refine_tol=0.0, bound_tol=0.0)
+                           stale_cg_limit=stale_cg_limit, method=meth, asm_max_active=asm_max_active,
+                           asm_max_rounds=asm_max_rounds, ipm_tol=ipm_tol, refine_tol=0.0, bound_tol=0.0)
         self._h = C.c_void_p()
         kp = Kunc.ctypes.data_as(C.c_void_p) if Kunc is not None else None
         _lib.check(lib.nnmpc_qp_create(C.byref(self._h), n, nu, n_aug,
                                        P.ctypes.data_as(C.c_void_p), tq.ctypes.data_as(C.c_void_p),
                                        kp, C.byref(opts)), "nnmpc_qp_create")
         self._lib = lib
+        if Hinv is not None:
+            Hinv = np.ascontiguousarray(Hinv, dtype=np.float64)
+            _lib.check(lib.nnmpc_qp_set_inverse(self._h, Hinv.ctypes.data_as(C.c_void_p),
+                                                Kunc.ctypes.data_as(C.c_void_p)), "nnmpc_qp_set_inverse")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -10,7 +10,7 @@ import os as _os
 name = sys.argv[1]; B = int(sys.argv[2]); nb = int(sys.argv[3]); slots = int(sys.argv[4]); sx = float(sys.argv[5]) if len(sys.argv) > 5 else 2.0
 pl = synthetic.plant(name, 0)
 t = time.time(); P, tq, nu = build_regulator_matrices(pl); print("condense s", time.time() - t, P.shape, flush=True)
-t = time.time(); qp = BatchedBoxQP(P, tq, nu, nb=nb, max_batch=slots, ipm_tol=float(_os.environ.get("IPM_TOL", "0")), stale_max_changes=int(_os.environ.get("STALE_CHG", "0")), stale_cg_limit=int(_os.environ.get("STALE_CG", "0")), sub_steps=int(_os.environ.get("SUBSTEPS", "0"))); print("create s", time.time() - t, flush=True)
+t = time.time(); qp = BatchedBoxQP(P, tq, nu, nb=nb, max_batch=slots, ipm_tol=float(_os.environ.get("IPM_TOL", "0")), stale_max_changes=int(_os.environ.get("STALE_CHG", "0")), stale_cg_limit=int(_os.environ.get("STALE_CG", "0")), sub_steps=int(_os.environ.get("SUBSTEPS", "0")), method=_os.environ.get("METHOD", "auto")); print("create s", time.time() - t, flush=True)
 s = synthetic.samples(pl, B, 1, sx)
 x0 = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), 1); lb = pl["ulb"].T - s["us"]; ub = pl["uub"].T - s["us"]
 out = qp.solve_batch(x0[:min(B, slots)], lb[:min(B, slots)], ub[:min(B, slots)])  # warmup

@@ -154,7 +154,9 @@ def test_warm_started_chains_equal_cold_and_save_factorizations():
     rng = np.random.default_rng(2)
     nc, T = 24, 10
     reg = lm.LinearMPCController.setup_regulator(pl["A"], pl["B"], pl["Q"], pl["R"], pl["S"], pl["N"], pl["ulb"], pl["uub"],
-                                                 max_batch=128)
+                                                 max_batch=128, solver_options=dict(method="pdip"))
+    reg_auto = lm.LinearMPCController.setup_regulator(pl["A"], pl["B"], pl["Q"], pl["R"], pl["S"], pl["N"], pl["ulb"],
+                                                      pl["uub"], max_batch=128)
 
     class FixedTarget:                       # target pairs given directly (the host target QP is tested elsewhere)
         def __init__(self, xs, us): self.xs, self.us = xs, us
@@ -171,3 +173,8 @@ def test_warm_started_chains_equal_cold_and_save_factorizations():
         assert np.abs(cold[k] - warm[k]).max() < 1e-8
     assert np.abs(cold["u"]).max() > 0.999                      # bounds are hit along the chains
     assert warm["factorizations"][:, 1:].sum() < cold["factorizations"][:, 1:].sum()
+    # default method (shared-inverse active-set pass, warm-started the same way): same chains, no n^3 work
+    auto = lm.simulate_chains(x0, u0, pl["A"], pl["B"], Bd, reg_auto, pl["ulb"], pl["uub"], ts, sp, ds, warm_start=True)
+    assert (auto["status"] == 0).all() and auto["factorizations"].sum() == 0
+    for k in ("x", "u", "uprev"):
+        assert np.abs(cold[k] - auto[k]).max() < 1e-8

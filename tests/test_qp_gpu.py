@@ -42,14 +42,17 @@ def test_factor_solve_kernels(name, nb):
 
 @pytest.mark.parametrize("name,seed,sx,nb", [("mini_cstrs", 0, 1.0, 64), ("mini_cdu", 1, 2.0, 64),
                                              ("mini_cdu", 1, 3.0, 128), ("cstrs", 3, 2.0, 64)])
-def test_solve_batch_matches_exact_optimum(name, seed, sx, nb):
+@pytest.mark.parametrize("method", ["pdip", "auto", "asm"])
+def test_solve_batch_matches_exact_optimum(name, seed, sx, nb, method):
     pl, reg = regulator_problem(name, seed)
     B = 48 if name.startswith("mini") else 12
     s, x0, lb, ub = batch_inputs(pl, B, seed + 10, sx)
     Uo, Ao = oracle_solve(reg, x0, lb, ub)
-    qp = _solver(reg, nb=nb, max_batch=128)
+    qp = _solver(reg, nb=nb, max_batch=128, method=method)
     out = qp.solve_batch(x0, lb, ub)
     assert (out["status"] == 0).all(), out["status"]
+    if method == "pdip":
+        assert (out["factorizations"] >= 1).all()
     err = np.abs(out["u"] - Uo).max(axis=1) / np.maximum(1.0, np.abs(Uo).max(axis=1))
     assert err.max() <= 1e-5, err      # north-star tolerance: 1e-5 relative
     assert err.max() <= 1e-8, err      # what the f64-refined polish actually delivers
