@@ -88,6 +88,11 @@ typedef struct {
   int64_t trsv_solves;       /* per-problem triangular solve pairs (L y = r, L'x = y) executed */
   int64_t asm_solved;        /* problems finished (and certified) by the active-set pass */
   int64_t asm_rounds;        /* lock-step rounds of the active-set pass */
+  int64_t asm_gemm_launches; /* launches of its dominant kernel (gemm_nt_f64_k: LAM * Hinv) */
+  double asm_gemm_ms;        /* hipEvent time of those (profiling on) */
+  double asm_gemm_flops;     /* algorithmic flops: 2 n^2 per running problem and round */
+  double asm_lambda_ms;      /* hipEvent time of asm_lambda_k */
+  double asm_update_ms;      /* hipEvent time of asm_update_k */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);

@@ -23,12 +23,14 @@
 
 namespace nnmpc {
 
-constexpr int ASM_MLDS = 192;      // largest active set factored in LDS (packed lower fp64)
+constexpr int ASM_MLDS = 176;      // largest active set factored in LDS (11 x 11 lower 16x16 fp64 tiles)
+constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: conflict-free MFMA operand reads)
 enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2 };
 
 struct AsmDev {
   int n, np, nu, nseg;
   int max_active;                  // larger sets -> fallback
+  int lds_cap;                     // largest set the LDS of this launch can factor (<= ASM_MLDS)
   int max_rounds;
   double bound_tol, stat_tol, pscale_unused;
   const double* H;                 // [np][np] fp64 inverse Hessian
@@ -44,9 +46,9 @@ struct AsmDev {
   const unsigned char* guess;      // [nseg][n] caller's active-set estimate or NULL
   int* state;                      // [nseg] ASM_RUN / DONE / FALLBACK
   int* rounds;                     // [nseg]
-  int* counters;                   // [0] still running, [1] big-set list length
+  int* counters;                   // [0] still running, [1] big-set list length, [2] largest set of the next round
   int* biglist;                    // [nseg] problems whose set does not fit LDS
-  double* scratch;                 // [pool][max_active*(max_active+1)/2]
+  double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
   double* u_out;
   uint32_t* act_out;
@@ -90,115 +92,209 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
   }
 }
 
-// Dense fp64 Cholesky S = L L' (packed lower, in place) + solve S lam = r, one workgroup.
-// Returns 0 on a non-positive pivot.
-__device__ int asm_chol_solve(double* S, double* r, int m, int tid) {
-  __shared__ int bad;
-  if (tid == 0) bad = 0;
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int c = 0; c < m; ++c) {
-    __syncthreads();
-    double piv = S[tri(c, c)];
-    if (!(piv > 0.0)) { piv = 1.0; if (tid == 0) bad = 1; }
-    const double sq = sqrt(piv), inv = 1.0 / sq;
-    for (int i = c + 1 + tid; i < m; i += 256) S[tri(i, c)] *= inv;
-    __syncthreads();
-    if (tid == 0) S[tri(c, c)] = sq;
-    for (int i = c + 1 + wave; i < m; i += 4) {
-      const double lic = S[tri(i, c)];
-      for (int j = c + 1 + lane; j <= i; j += 64) S[tri(i, j)] -= lic * S[tri(j, c)];
-    }
-  }
-  __syncthreads();
-  // triangular solves by wave 0 (wave-synchronous, no workgroup barriers)
-  if (wave == 0) {
-    for (int c = 0; c < m; ++c) {               // forward: L y = r
-      const double yc = r[c] / S[tri(c, c)];
-      for (int i = c + 1 + lane; i < m; i += 64) r[i] -= S[tri(i, c)] * yc;
-      if (lane == 0) r[c] = yc;
-    }
-    for (int c = m - 1; c >= 0; --c) {          // backward: L' lam = y
-      const double xc = r[c] / S[tri(c, c)];
-      for (int i = lane; i < c; i += 64) r[i] -= S[tri(c, i)] * xc;
-      if (lane == 0) r[c] = xc;
-    }
-  }
-  __syncthreads();
-  return !bad;
+// One problem: compact A, r_A = x_unc,A - b_A, S = H_AA as 16 x 16 fp64 tiles, blocked right-looking
+// Cholesky: diagonal tile + its inverse in the registers of wave 0 (rows on lanes, pivots by
+// v_readlane), TRSM and trailing updates on v_mfma_f64_16x16x4_f64 by all four waves, blocked
+// triangular solves by wave 0.  3 barriers per block column.
+// BIG = 0: one workgroup per problem, tiles in LDS (m <= lds_cap <= ASM_MLDS); larger sets are queued.
+// BIG = 1: persistent workgroups walk that queue with the tiles in a global scratch slab (L2-resident).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double rdlane_d(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ f64x4_t tile_mma_nt(const double* A, const double* B, int lane) {
+  f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int li = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[li * 17 + 4 * s + kq], B[li * 17 + 4 * s + kq], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ double* asm_tile(double* T, int I, int J) { return T + ((size_t)I * (I + 1) / 2 + J) * ASM_TS; }
 
-// One problem: compact A, r_A, S = H_AA, lam.   BIG = 0: S in LDS (m <= ASM_MLDS), problems with a
-// larger set are queued; BIG = 1: persistent workgroups walk that queue with S in global scratch.
 template <int BIG>
-__global__ __launch_bounds__(256) void asm_lambda_k(AsmDev d) {
+__global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int wsum[4];
-  __shared__ int s_m;
+  __shared__ int s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int* idx = reinterpret_cast<int*>(sm);                 // [max_active]
-  double* rA = sm + (d.max_active + 1) / 2;              // [max_active]
-  double* Sl = rA + d.max_active;                        // LDS S (BIG = 0)
+  const int cap = BIG ? d.max_active : ASM_MLDS;         // index / rhs capacity of this variant
+  int* idx = reinterpret_cast<int*>(sm);                 // [cap]
+  double* rA = sm + cap / 2;                             // [cap]
+  double* Yt = rA + cap;                                 // inverse of the current diagonal tile
+  double* T = BIG ? d.scratch + (size_t)blockIdx.x * ((size_t)(cap / 16) * (cap / 16 + 1) / 2 * ASM_TS)
+                  : Yt + ASM_TS;                         // lower tiles
   const int nbig = BIG ? d.counters[1] : 0;
   for (int it = blockIdx.x; BIG ? it < nbig : it == (int)blockIdx.x; it += gridDim.x) {
-    const int p = BIG ? d.biglist[it] : it;
-    if (!BIG && d.state[p] != ASM_RUN) return;
-    const size_t o = (size_t)p * d.np;
-    const unsigned char* st = d.st + (size_t)p * d.n;
-    // ---- ordered compaction of the active indices
-    const int per = (d.n + 255) / 256;
-    const int r0 = tid * per, r1 = min(d.n, r0 + per);
-    int c = 0;
-    for (int r = r0; r < r1; ++r) c += st[r] != 0;
-    int inc = c;
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int base = inc - c;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    const int m = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (m <= d.max_active) {
-      int k = base;
-      for (int r = r0; r < r1; ++r) if (st[r]) idx[k++] = r;
+  const int p = BIG ? d.biglist[it] : it;
+  if (!BIG && d.state[p] != ASM_RUN) return;
+  __syncthreads();                                       // previous queue item fully retired
+  const size_t o = (size_t)p * d.np;
+  const unsigned char* st = d.st + (size_t)p * d.n;
+  // ---- ordered compaction of the active indices
+  const int per = (d.n + 255) / 256;
+  const int r0 = tid * per, r1 = min(d.n, r0 + per);
+  int c = 0;
+  for (int r = r0; r < r1; ++r) c += st[r] != 0;
+  int inc = c;
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+  if (lane == 63) wsum[wave] = inc;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  int base = inc - c;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const int m = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (!BIG && m > d.lds_cap) {                  // handled by the queue kernel (or the PDIP path)
+    if (tid == 0) {
+      if (m > d.max_active) d.state[p] = ASM_FALLBACK;
+      else d.biglist[atomicAdd(&d.counters[1], 1)] = p;
     }
-    if (tid == 0) s_m = m;
-    __syncthreads();
-    if (m > d.max_active) {                     // too large for this path
-      if (tid == 0) d.state[p] = ASM_FALLBACK;
-      __syncthreads();
-      continue;
-    }
-    if (!BIG && m > ASM_MLDS) {                 // defer to the global-scratch kernel
-      if (tid == 0) d.biglist[atomicAdd(&d.counters[1], 1)] = p;
-      return;
-    }
-    double* S = BIG ? d.scratch + (size_t)blockIdx.x * ((size_t)d.max_active * (d.max_active + 1) / 2) : Sl;
-    for (int i = tid; i < m; i += 256) {
+    return;
+  }
+  {
+    int k = base;
+    for (int r = r0; r < r1; ++r) if (st[r]) idx[k++] = r;
+  }
+  const int mb = (m + 15) / 16;
+  __syncthreads();
+  for (int i = tid; i < mb * 16; i += 256) {
+    double v = 0.0;
+    if (i < m) {
       const int a = idx[i], k = a % d.nu;
-      const double b = st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k];
-      rA[i] = d.xunc[o + a] - b;
+      v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
     }
-    for (int i = wave; i < m; i += 4) {         // one wave per row of S: H[a_i][a_j], j <= i
-      const double* Hr = d.H + (size_t)idx[i] * d.np;
-      for (int j = lane; j <= i; j += 64) S[tri(i, j)] = Hr[idx[j]];
+    rA[i] = v;
+  }
+  // ---- gather S = H_AA into tiles (diagonal tiles complete, pad = identity)
+  const int ntile = mb * (mb + 1) / 2;
+  {
+    const int ti = tid >> 4, tj = tid & 15;
+    int I = 0, J = 0;
+    for (int t = 0; t < ntile; ++t) {
+      const int gi = 16 * I + ti, gj = 16 * J + tj;
+      double v = gi == gj ? 1.0 : 0.0;
+      if (gi < m && gj < m) v = d.H[(size_t)idx[gi] * d.np + idx[gj]];
+      asm_tile(T, I, J)[ti * 17 + tj] = v;
+      if (++J > I) { J = 0; ++I; }
     }
-    const int ok = asm_chol_solve(S, rA, m, tid);
-    if (!ok) { if (tid == 0) d.state[p] = ASM_FALLBACK; __syncthreads(); continue; }
-    // ---- dense multiplier row for the GEMM
-    for (int r = tid; r < d.np; r += 256) d.lam[o + r] = 0.0;
+  }
+  __syncthreads();
+  // ---- blocked Cholesky
+  for (int K = 0; K < mb; ++K) {
+    double* TKK = asm_tile(T, K, K);
+    if (wave == 0) {
+      const int row = lane & 15;
+      double a[16], y[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] = TKK[row * 17 + k];
+      int bad = 0;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) {
+        double dd = rdlane_d(a[cc], cc);
+        if (!(dd > 0.0)) { dd = 1.0; bad = 1; }
+        const double lc = a[cc] * (1.0 / sqrt(dd));
+        a[cc] = lc;
+#pragma unroll
+        for (int c2 = cc + 1; c2 < 16; ++c2) a[c2] -= lc * rdlane_d(lc, c2);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {            // lane (row) now acts as COLUMN `row` of Y = L^-1
+        double sacc = (r == row) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) sacc -= rdlane_d(a[k], r) * y[k];
+        y[r] = sacc / rdlane_d(a[r], r);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          TKK[row * 17 + k] = k <= row ? a[k] : 0.0;   // L_KK, strictly upper zero
+          Yt[k * 17 + row] = y[k];                     // Y[k][row]
+        }
+        if (bad && lane == 0) s_bad = 1;
+      }
+    }
     __syncthreads();
-    for (int i = tid; i < m; i += 256) d.lam[o + idx[i]] = rA[i];
+    for (int I = K + 1 + wave; I < mb; I += 4) {       // TRSM: T(I,K) <- T(I,K) Y'
+      double* TIK = asm_tile(T, I, K);
+      const f64x4_t acc = tile_mma_nt(TIK, Yt, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) TIK[((lane >> 4) + 4 * r) * 17 + (lane & 15)] = acc[r];
+    }
     __syncthreads();
+    {                                                   // trailing: T(I,J) -= T(I,K) T(J,K)'
+      int b = 0;
+      for (int I = K + 1; I < mb; ++I)
+        for (int J = K + 1; J <= I; ++J, ++b) {
+          if ((b & 3) != wave) continue;
+          const f64x4_t acc = tile_mma_nt(asm_tile(T, I, K), asm_tile(T, J, K), lane);
+          double* TIJ = asm_tile(T, I, J);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) TIJ[((lane >> 4) + 4 * r) * 17 + (lane & 15)] -= acc[r];
+        }
+    }
+    // keep Y_K for the solves: its transpose goes into the (now unused) strict upper part of T(K,K),
+    // its diagonal is 1 / L_KK's diagonal
+    if (wave == 0 && lane < 16) {
+      const int row = lane;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) if (k > row) TKK[row * 17 + k] = Yt[k * 17 + row];   // Y[k][row], k > row
+    }
+    __syncthreads();
+  }
+  if (s_bad) { if (tid == 0) d.state[p] = ASM_FALLBACK; continue; }
+  // ---- solves by wave 0:  L y = r (forward), L' lam = y (backward), 16-blocks
+  if (wave == 0) {
+    const int i = lane & 15, kq = lane >> 4;
+    for (int K = 0; K < mb; ++K) {                       // forward
+      double t = 0.0;
+      for (int J = 0; J < K; ++J) {
+        const double* TKJ = asm_tile(T, K, J);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += TKJ[i * 17 + 4 * kq + k] * rA[16 * J + 4 * kq + k];
+      }
+      t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+      t = rA[16 * K + i] - t;                            // all 64 lanes hold t_i (i = lane & 15)
+      // y_K = Y_K t,  Y_K[i][k] (k < i) stored at TKK[k][i], Y_K[i][i] = 1 / TKK[i][i]
+      const double* TKK = asm_tile(T, K, K);
+      double yv = t / TKK[i * 17 + i];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const double tk = __shfl(t, k); if (k < i) yv += TKK[k * 17 + i] * tk; }
+      if (lane < 16) rA[16 * K + i] = yv;
+    }
+    for (int K = mb - 1; K >= 0; --K) {                  // backward
+      double t = 0.0;
+      for (int I = K + 1; I < mb; ++I) {
+        const double* TIK = asm_tile(T, I, K);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += TIK[(4 * kq + k) * 17 + i] * rA[16 * I + 4 * kq + k];
+      }
+      t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+      t = rA[16 * K + i] - t;
+      // lam_K = Y_K' t:  lam_i = sum_{k >= i} Y_K[k][i] t_k,  Y_K[k][i] (k > i) stored at TKK[i][k]
+      const double* TKK = asm_tile(T, K, K);
+      double lv = t / TKK[i * 17 + i];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const double tk = __shfl(t, k); if (k > i) lv += TKK[i * 17 + k] * tk; }
+      if (lane < 16) rA[16 * K + i] = lv;
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < d.np; r += 256) d.lam[o + r] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) d.lam[o + idx[i]] = rA[i];
   }
 }
 
 // x from the GEMM result, fp64 KKT tests, next active set.
 __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
-  __shared__ int cnt[4];
+  __shared__ int cnt[8];
   const int p = blockIdx.x, tid = threadIdx.x;
   if (d.state[p] != ASM_RUN) return;
   const size_t o = (size_t)p * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
-  int chg = 0;
+  int chg = 0, nact = 0;
   for (int r = tid; r < d.n; r += 256) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
@@ -213,9 +309,10 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
       d.x[o + r] = s == 1 ? ub : lb;
       if ((s == 1 && l <= 0.0) || (s == 2 && l >= 0.0)) { st[r] = 0; ++chg; }   // keep iff multiplier > 0
     }
+    nact += st[r] != 0;
   }
-  for (int off = 32; off > 0; off >>= 1) chg += __shfl_xor(chg, off);
-  if ((tid & 63) == 0) cnt[tid >> 6] = chg;
+  for (int off = 32; off > 0; off >>= 1) { chg += __shfl_xor(chg, off); nact += __shfl_xor(nact, off); }
+  if ((tid & 63) == 0) { cnt[tid >> 6] = chg; cnt[4 + (tid >> 6)] = nact; }
   __syncthreads();
   if (tid == 0) {
     const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
@@ -223,7 +320,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
     d.rounds[p] = rd;
     if (tot == 0) d.state[p] = ASM_DONE;
     else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
-    else atomicAdd(&d.counters[0], 1);
+    else { atomicAdd(&d.counters[0], 1); atomicMax(&d.counters[2], cnt[4] + cnt[5] + cnt[6] + cnt[7]); }
   }
 }
 

@@ -675,6 +675,9 @@ void ev_collect(nnmpc_qp* h) {
     else if (r.kind == 1) h->stats.diag_ms += ms;
     else if (r.kind == 2) h->stats.trsv_ms += ms;
     else if (r.kind == 3) h->stats.total_ms += ms;
+    else if (r.kind == 4) h->stats.asm_lambda_ms += ms;
+    else if (r.kind == 5) { h->stats.asm_gemm_ms += ms; h->stats.asm_gemm_flops += r.flops; h->stats.asm_gemm_launches += 1; }
+    else if (r.kind == 6) h->stats.asm_update_ms += ms;
   }
   h->ev_recs.clear();
   h->ev_used = 0;
@@ -833,19 +836,36 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.biglist = h->asm_biglist; a.scratch = h->asm_scratch;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
-  const int lds_small = ((a.max_active + 1) / 2 + a.max_active + ASM_MLDS * (ASM_MLDS + 1) / 2) * 8;
-  const int lds_big = ((a.max_active + 1) / 2 + a.max_active) * 8;
-  int cnt[2] = {0, 0};
+  const int lds_big = (a.max_active / 2 + a.max_active + ASM_TS) * 8;
+  int cnt[4] = {0, 0, 0, 0};
   int rounds = 0;
+  int nrun = nprob;
+  int maxm = ASM_MLDS;       // largest active set expected this round (exact from round 1 on)
   for (; rounds < a.max_rounds + 1; ++rounds) {
-    HIPCHK(hipMemsetAsync(h->asm_counters, 0, 2 * sizeof(int), s));
-    hipLaunchKernelGGL((asm_lambda_k<0>), dim3(nprob), dim3(256), lds_small, s, a);
-    hipLaunchKernelGGL((asm_lambda_k<1>), dim3(h->asm_pool), dim3(256), lds_big, s, a);
-    gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, segp, h->np, h->np, h->asm_state, ASM_RUN);
-    hipLaunchKernelGGL(asm_update_k, dim3(nprob), dim3(256), 0, s, a);
-    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemsetAsync(h->asm_counters, 0, 4 * sizeof(int), s));
+    // LDS sized to the sets actually present: smaller sets -> more workgroups per CU
+    a.lds_cap = std::min(ASM_MLDS, std::max(32, ((maxm + 15) / 16) * 16));
+    const int mbc = a.lds_cap / 16;
+    const int lds_small = (ASM_MLDS / 2 + ASM_MLDS + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
+    {
+      EvScope es(h, 4, 0.0);
+      hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nprob), dim3(256), lds_small, s, a);
+      hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(h->asm_pool), dim3(256), lds_big, s, a);
+    }
+    {
+      // algorithmic flops: 2 np^2 per problem still running (nrun from the previous round's count)
+      EvScope es(h, 5, 2.0 * h->np * (double)h->np * nrun);
+      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, segp, h->np, h->np, h->asm_state, ASM_RUN);
+    }
+    {
+      EvScope es(h, 6, 0.0);
+      hipLaunchKernelGGL(asm_update_k, dim3(nprob), dim3(256), 0, s, a);
+    }
+    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     h->stats.asm_rounds += 1;
+    nrun = cnt[0];
+    maxm = cnt[2];
     if (cnt[0] == 0) break;
   }
   // certification with P itself: px = x P (only finished rows matter)
@@ -929,6 +949,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.stale_cg_limit <= 0) o.stale_cg_limit = 16;
   if (o.asm_max_active <= 0) o.asm_max_active = 768;
   if (o.asm_max_active > 768) o.asm_max_active = 768;
+  o.asm_max_active = std::max(16, (o.asm_max_active / 16) * 16);
   if (o.asm_max_rounds <= 0) o.asm_max_rounds = 40;
   if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
@@ -982,9 +1003,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->asm_pool = 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
-  A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, 2);
+  A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, 4);
   A_(h->asm_biglist, G); A_(h->asm_status, G);
-  A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)o.asm_max_active * (o.asm_max_active + 1) / 2));
+  A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
   d.n = n; d.np = np; d.nu = nu; d.slots = S; d.words = h->words;
@@ -1066,8 +1087,8 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
   }
   HIPCHK(hipMemcpy(h->H64, hh.data(), hh.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
-  const int lds_small = ((h->opts.asm_max_active + 1) / 2 + h->opts.asm_max_active + ASM_MLDS * (ASM_MLDS + 1) / 2) * 8;
-  HIPCHK(hipFuncSetAttribute((const void*)asm_lambda_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+  const int lds_small = (ASM_MLDS / 2 + ASM_MLDS + ASM_TS + (ASM_MLDS / 16) * (ASM_MLDS / 16 + 1) / 2 * ASM_TS) * 8;
+  HIPCHK(hipFuncSetAttribute((const void*)asm_lambda_tile_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
   h->have_inverse = true;
   return NNMPC_OK;
 }
