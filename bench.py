@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X dense f32 matrix/vector peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6   # f64 vector = matrix peak (half the f32 rate; v_mfma_f64_16x16x4_f64)
 
 
 def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s=30.0, workload="cdu"):
@@ -129,6 +130,10 @@ def main():
     ap.add_argument("--sx", type=float, default=2.0, help="state spread of the synthetic samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--method", default="auto", choices=["auto", "pdip", "asm"],
+                    help="auto: shared-inverse active-set pass + PDIP for what it leaves; pdip: PDIP path only")
+    ap.add_argument("--no-pdip", action="store_true", help="skip the extra PDIP-path measurement")
+    ap.add_argument("--pdip-batch", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -153,12 +158,12 @@ def main():
     from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
     from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
 
-    B = args.batch or (4096 if args.workload == "cdu" else 32768)
+    B = args.batch or (65536 if args.workload == "cdu" else 131072)
     slots = args.slots or (1024 if args.workload == "cdu" else 8192)
     pl = synthetic.plant(args.workload, seed=0)
     P, tq, nu = build_regulator_matrices(pl)
     n, n_aug, N = P.shape[0], tq.shape[1], pl["N"]
-    qp = BatchedBoxQP(P, tq, nu, max_batch=min(slots, B))
+    qp = BatchedBoxQP(P, tq, nu, max_batch=min(slots, B), method=args.method)
 
     # every rank draws its own shard of the seeded sample stream
     s = synthetic.samples(pl, B, seed=1000 + rank, sx=args.sx)
@@ -203,6 +208,26 @@ def main():
     st = qp.stats()
     status_h = status.cpu().numpy()
     iters_h = iters.cpu().numpy()
+    qp.set_profiling(False)
+
+    def panel_roofline(stx):
+        fl, ms = stx["panel_flops"], stx["panel_ms"]
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM traffic per launch: bytes per algorithmic flop measured with rocprofv3 PMC passes
+        # (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied; profiles/r01_pmc_chol_panel.json)
+        # scaled to this run's flops per launch; null when that profile does not exist.
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_chol_panel.json")
+        if args.workload == "cdu" and os.path.exists(pmc) and stx["panel_launches"]:
+            traffic = json.load(open(pmc))["hbm_bytes_per_algorithmic_flop"] * fl / stx["panel_launches"]
+        return {"kernel": "chol_panel_k", "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC-derived, see profiles/r01_pmc_chol_panel.json)",
+                "launches": stx["panel_launches"], "avg_launch_ms": ms / max(1, stx["panel_launches"]),
+                "time_share": {"chol_panel": ms / stx["total_ms"], "chol_diag": stx["diag_ms"] / stx["total_ms"],
+                               "trsv": stx["trsv_ms"] / stx["total_ms"]},
+                # whole-solve rate in the survey's dense-PDIP flop model: factorisations * n^3/3
+                "cholesky_flops_over_solve_time_TFLOPs": stx["factorizations"] * n ** 3 / 3 / (stx["total_ms"] * 1e-3) / 1e12}
 
     if rank == 0:
         out = {
@@ -211,33 +236,28 @@ def main():
             "value": world * B * args.steps / dt, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if st["asm_solved"] else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}_offline_data: synthetic {args.workload.upper()}-size plant "
-                                   f"(n={n} vars, m={2 * n} box rows, n_aug={n_aug}), {B} sampled x0 per GPU per step, "
-                                   f"waves of {min(slots, B)} resident problems",
-                       "batch_per_gpu": B, "sx": args.sx, "parallelism": f"dp{world} (sharded samples, 1 RCCL gather/step)"},
+                                   f"(n={n} vars, m={2 * n} box rows, n_aug={n_aug}), {B} sampled x0 per GPU per step",
+                       "batch_per_gpu": B, "sx": args.sx, "method": args.method,
+                       "parallelism": f"dp{world} (sharded samples, 1 RCCL gather/step)"},
             "solver": {"status_hist": np.bincount(status_h, minlength=3).tolist(),
-                       "mean_pdip_iters": float(iters_h[:, 0].mean()), "mean_factorizations": float(iters_h[:, 1].mean()),
-                       "max_factorizations": int(iters_h[:, 1].max()), "lockstep_rounds_per_step": st["rounds"] / args.steps},
+                       "solved_by_active_set_pass": int(st["asm_solved"]), "active_set_rounds_per_step": st["asm_rounds"] / args.steps,
+                       "solved_by_pdip_path": int(st["problems"] - st["asm_solved"]),
+                       "mean_pdip_iters": float(iters_h[:, 0].mean()), "mean_factorizations": float(iters_h[:, 1].mean())},
         }
-        # ---- roofline of the dominant kernel (chol_panel_k: MFMA f32), hipEvent-timed in the timed region
-        fl, ms = st["panel_flops"], st["panel_ms"]
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM traffic per launch: bytes per algorithmic flop measured with rocprofv3 PMC passes
-        # (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied; profiles/r01_pmc_chol_panel.json)
-        # scaled to this run's flops per launch; null when that profile does not exist.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_chol_panel.json")
-        if args.workload == "cdu" and os.path.exists(pmc) and st["panel_launches"]:
-            traffic = json.load(open(pmc))["hbm_bytes_per_algorithmic_flop"] * fl / st["panel_launches"]
-        out["roofline"] = {"kernel": "chol_panel_k", "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
-                           "traffic_unit": "HBM bytes per launch (PMC-derived, see profiles/r01_pmc_chol_panel.json)",
-                           "launches": st["panel_launches"], "avg_launch_ms": ms / max(1, st["panel_launches"]),
-                           "time_share": {"chol_panel": ms / st["total_ms"], "chol_diag": st["diag_ms"] / st["total_ms"],
-                                          "trsv": st["trsv_ms"] / st["total_ms"]},
-                           # whole-solve rate in the survey's dense-PDIP flop model: factorisations * n^3/3
-                           "cholesky_flops_over_solve_time_TFLOPs": st["factorizations"] * n ** 3 / 3 / (st["total_ms"] * 1e-3) / 1e12}
+        if st["asm_solved"]:
+            # dominant kernel of the shared-inverse active-set pass: gemm_nt_f64_k (LAM * P^-1), MFMA f64
+            ach = st["asm_gemm_flops"] / (st["asm_gemm_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "gemm_nt_f64_k (LAM * Pinv)", "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
+                               "launches": st["asm_gemm_launches"], "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]),
+                               "algorithmic_flops": "2 n^2 per problem still running, per round",
+                               "time_share": {"gemm_nt_f64 (LAM*Pinv)": st["asm_gemm_ms"] / st["total_ms"],
+                                              "asm_lambda_tile": st["asm_lambda_ms"] / st["total_ms"],
+                                              "asm_update": st["asm_update_ms"] / st["total_ms"]}}
+        else:
+            out["roofline"] = panel_roofline(st)
         # ---- parity spot check against the fp64 oracle on the first problems of the batch
         if not args.no_parity:
             from oracle import qp as oqp
@@ -255,6 +275,28 @@ def main():
                 errs.append(float(np.abs(u_h[b] - xe).max() / max(1.0, np.abs(xe).max())))
                 ham += int((bits != rows).sum())
             out["parity"] = {"checked": k, "max_rel_err_vs_fp64_oracle": max(errs), "active_set_hamming": ham}
+        # ---- the PDIP path (method="pdip") on the head of the same batch, with its own roofline
+        if args.method == "auto" and not args.no_pdip:
+            Bp = min(B, args.pdip_batch or (2048 if args.workload == "cdu" else 16384))
+            qp2 = BatchedBoxQP(P, tq, nu, max_batch=min(slots, Bp), method="pdip")
+            u2 = torch.empty((Bp, n), dtype=torch.float64, device=dev)
+            act2 = torch.empty((Bp, qp.words), dtype=torch.int32, device=dev)
+            st2 = torch.empty((Bp,), dtype=torch.int32, device=dev)
+            it2 = torch.empty((Bp, 2), dtype=torch.int32, device=dev)
+            qp2.solve_batch_device(min(Bp, 256), x0, lb, ub, u2, act2, st2, it2)      # warm-up
+            qp2.set_profiling(True); qp2.stats(reset=True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            qp2.solve_batch_device(Bp, x0, lb, ub, u2, act2, st2, it2)
+            torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+            s2 = qp2.stats()
+            it2h = it2.cpu().numpy()
+            out["pdip_path"] = {"value": Bp / dt2, "unit": "solves/s", "batch": Bp, "dtype": "f32 (+f64 refinement)",
+                                "status_hist": np.bincount(st2.cpu().numpy(), minlength=3).tolist(),
+                                "mean_pdip_iters": float(it2h[:, 0].mean()), "mean_factorizations": float(it2h[:, 1].mean()),
+                                "max_abs_diff_vs_active_set_pass": float((u2 - u[:Bp]).abs().max()),
+                                "active_sets_equal": bool(torch.equal(act2, act[:Bp])),
+                                "roofline": panel_roofline(s2)}
+            qp2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, x0_h, lb_h, ub_h,
                                                budget_s=20.0 if args.workload == "cdu" else 10.0, workload=args.workload)
