@@ -252,7 +252,7 @@ def main():
             out["roofline"] = {"kernel": "gemm_nt_f64_k (LAM * Pinv)", "bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
                                "launches": st["asm_gemm_launches"], "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]),
-                               "algorithmic_flops": "2 n^2 per problem still running, per round",
+                               "algorithmic_flops": "2 n k_max per problem still running and round (k_max = last active bound of the round)",
                                "time_share": {"gemm_nt_f64 (LAM*Pinv)": st["asm_gemm_ms"] / st["total_ms"],
                                               "asm_lambda_tile": st["asm_lambda_ms"] / st["total_ms"],
                                               "asm_update": st["asm_update_ms"] / st["total_ms"]}}

@@ -50,8 +50,11 @@ static __global__ __launch_bounds__(256) void gemm_nt_f64_k(double* __restrict__
                                                      const double* __restrict__ A, size_t lda,
                                                      const double* __restrict__ B, size_t ldb,
                                                      int K, const int* __restrict__ rowphase,
-                                                     int want) {
+                                                     int want, const int* __restrict__ kdyn = nullptr) {
   constexpr int LD = 18;
+  // kdyn (nullable): device-side bound on the non-zero columns of A (last non-zero column index);
+  // the k-loop stops there -- LAM rows of the active-set pass are zero beyond the last active bound
+  if (kdyn) K = min(K, ((*kdyn + 16) / 16) * 16);
   __shared__ __attribute__((aligned(16))) double As[2][64 * LD];
   __shared__ __attribute__((aligned(16))) double Bs[2][64 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -46,7 +46,8 @@ struct AsmDev {
   const unsigned char* guess;      // [nseg][n] caller's active-set estimate or NULL
   int* state;                      // [nseg] ASM_RUN / DONE / FALLBACK
   int* rounds;                     // [nseg]
-  int* counters;                   // [0] still running, [1] big-set list length, [2] largest set of the next round
+  int* counters;                   // [0] still running, [1] big-set list length, [2] largest set of the next
+                                   // round, [3] largest active variable index of this round (GEMM k-range)
   int* biglist;                    // [nseg] problems whose set does not fit LDS
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
   for (int r = tid; r < d.np; r += 256) d.lam[o + r] = 0.0;
   __syncthreads();
   for (int i = tid; i < m; i += 256) d.lam[o + idx[i]] = rA[i];
+  if (tid == 0 && m > 0) atomicMax(&d.counters[3], idx[m - 1]);
   }
 }
 

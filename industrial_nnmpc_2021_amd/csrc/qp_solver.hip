@@ -696,9 +696,10 @@ void gemm32(nnmpc_qp* h, float* C, size_t ldc, const float* A, size_t lda, const
   else launch_gemm32<64>(h->stream, C, ldc, A, lda, B, ldb, M, N, K);
 }
 void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, const double* B,
-            size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0) {
+            size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0,
+            const int* kdyn = nullptr) {
   dim3 grid(N / 64, M / 64);
-  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want);
+  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want, kdyn);
 }
 
 template <int NB>
@@ -854,8 +855,9 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
     {
       // algorithmic flops: 2 np^2 per problem still running (nrun from the previous round's count)
-      EvScope es(h, 5, 2.0 * h->np * (double)h->np * nrun);
-      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, segp, h->np, h->np, h->asm_state, ASM_RUN);
+      EvScope es(h, 5, 0.0);   // flops are added after the round's counters are read back
+      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, segp, h->np, h->np, h->asm_state, ASM_RUN,
+             h->asm_counters + 3);
     }
     {
       EvScope es(h, 6, 0.0);
@@ -864,6 +866,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     h->stats.asm_rounds += 1;
+    // algorithmic flops of this round's LAM * Pinv: 2 * n * (columns up to the last active bound) per running problem
+    h->stats.asm_gemm_flops += 2.0 * h->np * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun;
     nrun = cnt[0];
     maxm = cnt[2];
     if (cnt[0] == 0) break;
