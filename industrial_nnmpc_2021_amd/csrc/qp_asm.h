@@ -171,14 +171,23 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
   // ---- gather S = H_AA into tiles (diagonal tiles complete, pad = identity)
   const int ntile = mb * (mb + 1) / 2;
   {
+    // thread (ti, tj) fetches element (ti, tj) of every tile; 4 tiles per trip keep 4 loads in flight
     const int ti = tid >> 4, tj = tid & 15;
     int I = 0, J = 0;
-    for (int t = 0; t < ntile; ++t) {
-      const int gi = 16 * I + ti, gj = 16 * J + tj;
-      double v = gi == gj ? 1.0 : 0.0;
-      if (gi < m && gj < m) v = d.H[(size_t)idx[gi] * d.np + idx[gj]];
-      asm_tile(T, I, J)[ti * 17 + tj] = v;
-      if (++J > I) { J = 0; ++I; }
+    for (int t0 = 0; t0 < ntile; t0 += 4) {
+      double v[4];
+      int tI[4], tJ[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        tI[u] = I; tJ[u] = J;
+        const int gi = 16 * I + ti, gj = 16 * J + tj;
+        v[u] = gi == gj ? 1.0 : 0.0;
+        if (t0 + u < ntile && gi < m && gj < m) v[u] = d.H[(size_t)idx[gi] * d.np + idx[gj]];
+        if (++J > I) { J = 0; ++I; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (t0 + u < ntile) asm_tile(T, tI[u], tJ[u])[ti * 17 + tj] = v[u];
     }
   }
   __syncthreads();
@@ -186,33 +195,46 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
   for (int K = 0; K < mb; ++K) {
     double* TKK = asm_tile(T, K, K);
     if (wave == 0) {
+      // rows on lanes (lanes 16..63 mirror 0..15); the scaled pivot column travels through a
+      // 16-double LDS line (one ds_write + broadcast ds_reads per step), no fp64 divisions
       const int row = lane & 15;
-      double a[16], y[16];
+      double a[16], y[16], invd[16];
+      double* colb = Yt;                               // Yt is rewritten below, free until then
 #pragma unroll
       for (int k = 0; k < 16; ++k) a[k] = TKK[row * 17 + k];
       int bad = 0;
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) {
-        double dd = rdlane_d(a[cc], cc);
+        if (lane == cc) colb[16] = a[cc];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lanes exchange through LDS: no forwarding across this point
+        double dd = colb[16];
         if (!(dd > 0.0)) { dd = 1.0; bad = 1; }
-        const double lc = a[cc] * (1.0 / sqrt(dd));
+        const double inv = rsqrt(dd);
+        invd[cc] = inv;
+        const double lc = a[cc] * inv;
         a[cc] = lc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads of the previous column done before it is overwritten
+        if (lane < 16) colb[row] = lc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int c2 = cc + 1; c2 < 16; ++c2) a[c2] -= lc * rdlane_d(lc, c2);
+        for (int c2 = cc + 1; c2 < 16; ++c2) a[c2] -= lc * colb[c2];
       }
+      // Y = L^-1: lane `row` computes COLUMN `row`;  L[r][k] (uniform) is read from the tile in LDS
+      if (lane < 16) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {            // lane (row) now acts as COLUMN `row` of Y = L^-1
+        for (int k = 0; k < 16; ++k) TKK[row * 17 + k] = k <= row ? a[k] : 0.0;   // L_KK, strict upper zero
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         double sacc = (r == row) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < r; ++k) sacc -= rdlane_d(a[k], r) * y[k];
-        y[r] = sacc / rdlane_d(a[r], r);
+        for (int k = 0; k < r; ++k) sacc -= TKK[r * 17 + k] * y[k];
+        y[r] = sacc * invd[r];
       }
       if (lane < 16) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          TKK[row * 17 + k] = k <= row ? a[k] : 0.0;   // L_KK, strictly upper zero
-          Yt[k * 17 + row] = y[k];                     // Y[k][row]
-        }
+        for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = y[k];                     // Y[k][row]
         if (bad && lane == 0) s_bad = 1;
       }
     }
@@ -263,6 +285,7 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) { const double tk = __shfl(t, k); if (k < i) yv += TKK[k * 17 + i] * tk; }
       if (lane < 16) rA[16 * K + i] = yv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // y_K visible to every lane before the next block row
     }
     for (int K = mb - 1; K >= 0; --K) {                  // backward
       double t = 0.0;
@@ -279,6 +302,7 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) { const double tk = __shfl(t, k); if (k > i) lv += TKK[i * 17 + k] * tk; }
       if (lane < 16) rA[16 * K + i] = lv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
   __syncthreads();

@@ -23,6 +23,7 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "../../include/nnmpc.h"
 #include "chol_kernels.h"
 #include "gemm_kernels.h"
