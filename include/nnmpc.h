@@ -123,8 +123,10 @@ int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const do
 /* Enables the shared-inverse active-set pass: Hinv = P^-1 (n x n, fp64), Kunc = -Hinv tq (n x n_aug).
  * All samples share P (reference lib/linearMPC.py:472), so on an active set A the equality-constrained
  * optimum is x = x_unc - Hinv[:,A] lam with lam = (Hinv_AA)^-1 (x_unc,A - b_A): a primal-dual active-set
- * iteration needs no n^3 factorisation.  Results are certified against P in fp64; problems the pass
- * cannot finish go through the PDIP path. */
+ * iteration needs no n^3 factorisation.  The inverse is verified once on the device (|P Pinv - I|,
+ * |P Kunc + tq|); those bounds certify each result's KKT residual and multiplier signs, results too
+ * close to call are re-checked against P itself in fp64, and problems the pass cannot finish go
+ * through the PDIP path. */
 int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc);
 
 int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on);

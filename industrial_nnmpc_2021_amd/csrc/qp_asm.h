@@ -25,14 +25,18 @@ namespace nnmpc {
 
 constexpr int ASM_MLDS = 176;      // largest active set factored in LDS (11 x 11 lower 16x16 fp64 tiles)
 constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: conflict-free MFMA operand reads)
-enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2 };
+enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3 };   // CERT: finished and certified by the inverse-error bound
+constexpr int ASM_NBIN = 3;
+__host__ __device__ constexpr int asm_bin_cap(int b) { return b == 0 ? 96 : (b == 1 ? 128 : ASM_MLDS); }
 
 struct AsmDev {
   int n, np, nu, nseg;
   int max_active;                  // larger sets -> fallback
-  int lds_cap;                     // largest set the LDS of this launch can factor (<= ASM_MLDS)
   int max_rounds;
-  double bound_tol, stat_tol, pscale_unused;
+  double bound_tol, stat_tol, pscale;
+  double e1max, e2max;             // max |P Kunc + tq|, max |P Pinv - I| (verified once at setup)
+  const double* x0;                // [nseg][ka] padded initial states (for the certificate)
+  int ka;
   const double* H;                 // [np][np] fp64 inverse Hessian
   const double* lb;                // [nseg][nu]
   const double* ub;
@@ -46,9 +50,12 @@ struct AsmDev {
   const unsigned char* guess;      // [nseg][n] caller's active-set estimate or NULL
   int* state;                      // [nseg] ASM_RUN / DONE / FALLBACK
   int* rounds;                     // [nseg]
-  int* counters;                   // [0] still running, [1] big-set list length, [2] largest set of the next
-                                   // round, [3] largest active variable index of this round (GEMM k-range)
+  int* counters;                   // [0] still running, [1] big-set list length, [3] largest active variable
+                                   // index of this round (GEMM k-range), [4 + b] length of size-bin list b
   int* biglist;                    // [nseg] problems whose set does not fit LDS
+  int* binlist;                    // [ASM_NBIN][nseg] problems by active-set size (LDS size / occupancy classes)
+  int* idxg;                       // [nseg][max_active] ordered active indices (asm_count_k)
+  int* mg;                         // [nseg] their number
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
   double* u_out;
@@ -93,12 +100,47 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
   }
 }
 
-// One problem: compact A, r_A = x_unc,A - b_A, S = H_AA as 16 x 16 fp64 tiles, blocked right-looking
+// Round stage 0: ordered list of the active indices of every running problem, its length, the
+// size class (which fixes the LDS footprint, hence the occupancy, of the factorisation kernel).
+__global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
+  __shared__ int wsum[4];
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (d.state[p] != ASM_RUN) return;
+  const unsigned char* st = d.st + (size_t)p * d.n;
+  const int per = (d.n + 255) / 256;
+  const int r0 = tid * per, r1 = min(d.n, r0 + per);
+  int c = 0;
+  for (int r = r0; r < r1; ++r) c += st[r] != 0;
+  int inc = c;
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = inc - c;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const int m = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (m <= d.max_active) {
+    int* idx = d.idxg + (size_t)p * d.max_active;
+    int k = base;
+    for (int r = r0; r < r1; ++r) if (st[r]) idx[k++] = r;
+    if (k == m && c > 0) atomicMax(&d.counters[3], r1 > r0 ? idx[m - 1] : 0);   // thread holding the last index
+  }
+  if (tid == 0) {
+    d.mg[p] = m;
+    if (m > d.max_active) d.state[p] = ASM_FALLBACK;
+    else if (m > ASM_MLDS) d.biglist[atomicAdd(&d.counters[1], 1)] = p;
+    else {
+      const int b = m <= asm_bin_cap(0) ? 0 : (m <= asm_bin_cap(1) ? 1 : 2);
+      d.binlist[(size_t)b * d.nseg + atomicAdd(&d.counters[4 + b], 1)] = p;
+    }
+  }
+}
+
+// One problem: r_A = x_unc,A - b_A, S = H_AA as 16 x 16 fp64 tiles, blocked right-looking
 // Cholesky: diagonal tile + its inverse in the registers of wave 0 (rows on lanes, pivots by
 // v_readlane), TRSM and trailing updates on v_mfma_f64_16x16x4_f64 by all four waves, blocked
 // triangular solves by wave 0.  3 barriers per block column.
-// BIG = 0: one workgroup per problem, tiles in LDS (m <= lds_cap <= ASM_MLDS); larger sets are queued.
-// BIG = 1: persistent workgroups walk that queue with the tiles in a global scratch slab (L2-resident).
+// BIG = 0: one workgroup per entry of size-bin list `bin`, tiles in LDS sized for that bin.
+// BIG = 1: persistent workgroups walk the big-set queue with the tiles in a global scratch slab (L2).
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double rdlane_d(double x, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
@@ -116,48 +158,25 @@ __device__ __forceinline__ f64x4_t tile_mma_nt(const double* A, const double* B,
 __device__ __forceinline__ double* asm_tile(double* T, int I, int J) { return T + ((size_t)I * (I + 1) / 2 + J) * ASM_TS; }
 
 template <int BIG>
-__global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
+__global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d, int bin) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int wsum[4];
   __shared__ int s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cap = BIG ? d.max_active : ASM_MLDS;         // index / rhs capacity of this variant
-  int* idx = reinterpret_cast<int*>(sm);                 // [cap]
-  double* rA = sm + cap / 2;                             // [cap]
+  const int cap = BIG ? d.max_active : asm_bin_cap(bin);  // rhs capacity of this variant
+  double* rA = sm;                                       // [cap]
   double* Yt = rA + cap;                                 // inverse of the current diagonal tile
   double* T = BIG ? d.scratch + (size_t)blockIdx.x * ((size_t)(cap / 16) * (cap / 16 + 1) / 2 * ASM_TS)
                   : Yt + ASM_TS;                         // lower tiles
-  const int nbig = BIG ? d.counters[1] : 0;
-  for (int it = blockIdx.x; BIG ? it < nbig : it == (int)blockIdx.x; it += gridDim.x) {
-  const int p = BIG ? d.biglist[it] : it;
-  if (!BIG && d.state[p] != ASM_RUN) return;
+  const int nitem = BIG ? d.counters[1] : d.counters[4 + bin];
+  const int* list = BIG ? d.biglist : d.binlist + (size_t)bin * d.nseg;
+  for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
+  const int p = list[it];
   __syncthreads();                                       // previous queue item fully retired
+  if (tid == 0) s_bad = 0;
   const size_t o = (size_t)p * d.np;
   const unsigned char* st = d.st + (size_t)p * d.n;
-  // ---- ordered compaction of the active indices
-  const int per = (d.n + 255) / 256;
-  const int r0 = tid * per, r1 = min(d.n, r0 + per);
-  int c = 0;
-  for (int r = r0; r < r1; ++r) c += st[r] != 0;
-  int inc = c;
-  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-  if (lane == 63) wsum[wave] = inc;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  int base = inc - c;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  const int m = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  if (!BIG && m > d.lds_cap) {                  // handled by the queue kernel (or the PDIP path)
-    if (tid == 0) {
-      if (m > d.max_active) d.state[p] = ASM_FALLBACK;
-      else d.biglist[atomicAdd(&d.counters[1], 1)] = p;
-    }
-    return;
-  }
-  {
-    int k = base;
-    for (int r = r0; r < r1; ++r) if (st[r]) idx[k++] = r;
-  }
+  const int* idx = d.idxg + (size_t)p * d.max_active;
+  const int m = d.mg[p];
   const int mb = (m + 15) / 16;
   __syncthreads();
   for (int i = tid; i < mb * 16; i += 256) {
@@ -306,25 +325,31 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d) {
     }
   }
   __syncthreads();
-  for (int r = tid; r < d.np; r += 256) d.lam[o + r] = 0.0;
-  __syncthreads();
-  for (int i = tid; i < m; i += 256) d.lam[o + idx[i]] = rA[i];
-  if (tid == 0 && m > 0) atomicMax(&d.counters[3], idx[m - 1]);
+  for (int i = tid; i < m; i += 256) d.lam[o + idx[i]] = rA[i];     // the rest of the row is zero (asm_update_k)
   }
 }
 
-// x from the GEMM result, fp64 KKT tests, next active set.
+// x from the GEMM result, fp64 KKT tests, next active set.  A problem whose set no longer changes
+// is certified right here when the verified inverse allows it:  with E1 = P Kunc + tq and
+// E2 = P Pinv - I (maxima e1max, e2max computed once at setup),
+//     P x + q = E1 x0 - lam_ext - E2 lam_ext,
+// so |stationarity residual on the free set| <= e1max |x0|_1 + e2max |lam|_1 =: bnd, and the
+// multiplier signs are certain when every |lam_a| > bnd.  Otherwise (ASM_DONE) the full check
+// with P itself (asm_certify_k) decides.
 __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
-  __shared__ int cnt[8];
+  __shared__ int cnt[4];
+  __shared__ double red[12];
   const int p = blockIdx.x, tid = threadIdx.x;
   if (d.state[p] != ASM_RUN) return;
   const size_t o = (size_t)p * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
-  int chg = 0, nact = 0;
+  int chg = 0;
+  double l1 = 0.0, lmin = 1e300, qinf = 0.0;
   for (int r = tid; r < d.n; r += 256) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     const int s = st[r];
+    qinf = fmax(qinf, fabs(d.q64[o + r]));
     if (s == 0) {
       const double x = d.xunc[o + r] - d.xh[o + r];
       d.x[o + r] = x;
@@ -332,21 +357,43 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
       else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
     } else {
       const double l = d.lam[o + r];
+      d.lam[o + r] = 0.0;                                    // keep the LAM rows zero outside the next set
       d.x[o + r] = s == 1 ? ub : lb;
+      l1 += fabs(l); lmin = fmin(lmin, fabs(l));
       if ((s == 1 && l <= 0.0) || (s == 2 && l >= 0.0)) { st[r] = 0; ++chg; }   // keep iff multiplier > 0
     }
-    nact += st[r] != 0;
   }
-  for (int off = 32; off > 0; off >>= 1) { chg += __shfl_xor(chg, off); nact += __shfl_xor(nact, off); }
-  if ((tid & 63) == 0) { cnt[tid >> 6] = chg; cnt[4 + (tid >> 6)] = nact; }
+  double x1 = 0.0;
+  for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
+  for (int off = 32; off > 0; off >>= 1) {
+    chg += __shfl_xor(chg, off);
+    l1 += __shfl_xor(l1, off); x1 += __shfl_xor(x1, off);
+    lmin = fmin(lmin, __shfl_xor(lmin, off)); qinf = fmax(qinf, __shfl_xor(qinf, off));
+  }
+  if ((tid & 63) == 0) {
+    const int w = tid >> 6;
+    cnt[w] = chg; red[w] = l1; red[4 + w] = x1; red[8 + w] = lmin;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) cnt[tid >> 6] += 0;
+  __syncthreads();
+  const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  // qinf needs its own slot: reuse via a second pass
+  __shared__ double qred[4];
+  if ((tid & 63) == 0) qred[tid >> 6] = qinf;
   __syncthreads();
   if (tid == 0) {
-    const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     const int rd = d.rounds[p] + 1;
     d.rounds[p] = rd;
-    if (tot == 0) d.state[p] = ASM_DONE;
-    else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
-    else { atomicAdd(&d.counters[0], 1); atomicMax(&d.counters[2], cnt[4] + cnt[5] + cnt[6] + cnt[7]); }
+    if (tot == 0) {
+      const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
+      const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
+      const double QI = fmax(fmax(qred[0], qred[1]), fmax(qred[2], qred[3]));
+      const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
+      const bool sure = bnd <= d.stat_tol * fmax(d.pscale, QI) && LM > bnd;
+      d.state[p] = sure ? ASM_CERT : ASM_DONE;
+    } else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
+    else atomicAdd(&d.counters[0], 1);
   }
 }
 
@@ -356,7 +403,8 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
   __shared__ int cnt[4];
   __shared__ double gq[4];
   const int p = blockIdx.x, tid = threadIdx.x;
-  if (d.state[p] != ASM_DONE) {
+  const int stt = d.state[p];
+  if (stt != ASM_DONE && stt != ASM_CERT) {
     if (tid == 0 && d.status_out) d.status_out[p] = 3;   // marks "not solved here" for the caller
     return;
   }
@@ -367,12 +415,15 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
   for (int r = tid; r < d.n; r += 256) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
-    const double x = d.x[o + r], g = d.px[o + r] + d.q64[o + r];
+    const double x = d.x[o + r];
     const int s = st[r];
-    qm = fmax(qm, fabs(d.q64[o + r]));
-    if (s == 0) { gf = fmax(gf, fabs(g)); bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); }
-    else if (s == 1) bad += g >= 0.0;
-    else bad += g <= 0.0;
+    if (stt == ASM_DONE) {                      // full check with P itself
+      const double g = d.px[o + r] + d.q64[o + r];
+      qm = fmax(qm, fabs(d.q64[o + r]));
+      if (s == 0) { gf = fmax(gf, fabs(g)); bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); }
+      else if (s == 1) bad += g >= 0.0;
+      else bad += g <= 0.0;
+    }
     d.u_out[(size_t)p * d.n + r] = x;
   }
   for (int off = 32; off > 0; off >>= 1) {

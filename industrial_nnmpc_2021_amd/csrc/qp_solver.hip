@@ -614,8 +614,9 @@ struct nnmpc_qp {
   double* Kunc64;   // np x ka
   double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch;
   unsigned char* asm_st;
-  int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status;
+  int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg;
   int asm_pool;
+  double asm_e1max, asm_e2max;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
   double* x0_64;        // [seg_max][ka]
   float* x0_32;
@@ -831,31 +832,34 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   AsmDev a;
   a.n = h->n; a.np = h->np; a.nu = h->nu; a.nseg = nprob;
   a.max_active = h->opts.asm_max_active; a.max_rounds = h->opts.asm_max_rounds;
-  a.bound_tol = h->opts.bound_tol; a.stat_tol = 1e-8; a.pscale_unused = 0.0;
+  a.bound_tol = h->opts.bound_tol; a.stat_tol = 1e-8; a.pscale = h->pscale;
+  a.e1max = h->asm_e1max; a.e2max = h->asm_e2max; a.x0 = h->x0_64; a.ka = h->ka;
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.scratch = h->asm_scratch;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.scratch = h->asm_scratch;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
+  a.nseg = nprob;
+  HIPCHK(hipMemsetAsync(h->asm_lam, 0, (size_t)segp * h->np * sizeof(double), s));
   hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
-  const int lds_big = (a.max_active / 2 + a.max_active + ASM_TS) * 8;
-  int cnt[4] = {0, 0, 0, 0};
+  const int lds_big = (a.max_active + ASM_TS) * 8;
+  int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int rounds = 0;
   int nrun = nprob;
-  int maxm = ASM_MLDS;       // largest active set expected this round (exact from round 1 on)
   for (; rounds < a.max_rounds + 1; ++rounds) {
-    HIPCHK(hipMemsetAsync(h->asm_counters, 0, 4 * sizeof(int), s));
-    // LDS sized to the sets actually present: smaller sets -> more workgroups per CU
-    a.lds_cap = std::min(ASM_MLDS, std::max(32, ((maxm + 15) / 16) * 16));
-    const int mbc = a.lds_cap / 16;
-    const int lds_small = (ASM_MLDS / 2 + ASM_MLDS + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
+    HIPCHK(hipMemsetAsync(h->asm_counters, 0, 8 * sizeof(int), s));
     {
       EvScope es(h, 4, 0.0);
-      hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nprob), dim3(256), lds_small, s, a);
-      hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(h->asm_pool), dim3(256), lds_big, s, a);
+      hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
+      // one launch per size class: the LDS footprint (hence the workgroups per CU) follows the class
+      for (int b = 0; b < ASM_NBIN; ++b) {
+        const int mbc = asm_bin_cap(b) / 16;
+        const int lds = (asm_bin_cap(b) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
+        hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nrun), dim3(256), lds, s, a, b);
+      }
+      hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(h->asm_pool), dim3(256), lds_big, s, a, 0);
     }
     {
-      // algorithmic flops: 2 np^2 per problem still running (nrun from the previous round's count)
       EvScope es(h, 5, 0.0);   // flops are added after the round's counters are read back
       gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, segp, h->np, h->np, h->asm_state, ASM_RUN,
              h->asm_counters + 3);
@@ -864,13 +868,12 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       EvScope es(h, 6, 0.0);
       hipLaunchKernelGGL(asm_update_k, dim3(nprob), dim3(256), 0, s, a);
     }
-    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     h->stats.asm_rounds += 1;
     // algorithmic flops of this round's LAM * Pinv: 2 * n * (columns up to the last active bound) per running problem
     h->stats.asm_gemm_flops += 2.0 * h->np * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun;
     nrun = cnt[0];
-    maxm = cnt[2];
     if (cnt[0] == 0) break;
   }
   // certification with P itself: px = x P (only finished rows matter)
@@ -1008,8 +1011,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->asm_pool = 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
-  A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, 4);
-  A_(h->asm_biglist, G); A_(h->asm_status, G);
+  A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, 8);
+  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NBIN * G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
@@ -1092,8 +1096,39 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
   }
   HIPCHK(hipMemcpy(h->H64, hh.data(), hh.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
-  const int lds_small = (ASM_MLDS / 2 + ASM_MLDS + ASM_TS + (ASM_MLDS / 16) * (ASM_MLDS / 16 + 1) / 2 * ASM_TS) * 8;
-  HIPCHK(hipFuncSetAttribute((const void*)asm_lambda_tile_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+  // ---- verify the inverse once, on the device copies the solves will use:
+  //      E2 = P Pinv - I,  E1 = P Kunc + tq;  their maxima feed the per-problem certificate
+  {
+    const int kap = ((n_aug + 63) / 64) * 64;
+    double *tmp = nullptr, *kt = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)np * np * 8));
+    HIPCHK(hipMalloc((void**)&kt, (size_t)kap * np * 8));
+    std::vector<double> ktr((size_t)kap * np, 0.0);
+    for (int r = 0; r < n; ++r)
+      for (int k = 0; k < n_aug; ++k) ktr[(size_t)k * np + r] = Kunc[(size_t)r * n_aug + k];
+    HIPCHK(hipMemcpy(kt, ktr.data(), ktr.size() * 8, hipMemcpyHostToDevice));
+    gemm64(h, tmp, np, h->P64, np, h->H64, np, np, np, np);                 // P Pinv (Pinv symmetric)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> c((size_t)np * np);
+    HIPCHK(hipMemcpy(c.data(), tmp, c.size() * 8, hipMemcpyDeviceToHost));
+    double e2 = 0.0;
+    for (int r = 0; r < n; ++r)
+      for (int cc = 0; cc < n; ++cc) e2 = std::max(e2, std::fabs(c[(size_t)r * np + cc] - (r == cc ? 1.0 : 0.0)));
+    gemm64(h, tmp, kap, h->P64, np, kt, np, np, kap, np);                   // P Kunc  -> [np][kap]
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(c.data(), tmp, (size_t)np * kap * 8, hipMemcpyDeviceToHost));
+    std::vector<double> tqh((size_t)np * ka);
+    HIPCHK(hipMemcpy(tqh.data(), h->tq64, tqh.size() * 8, hipMemcpyDeviceToHost));
+    double e1 = 0.0;
+    for (int r = 0; r < n; ++r)
+      for (int k = 0; k < n_aug; ++k) e1 = std::max(e1, std::fabs(c[(size_t)r * kap + k] + tqh[(size_t)r * ka + k]));
+    hipFree(tmp); hipFree(kt);
+    h->asm_e1max = e1; h->asm_e2max = e2;
+    if (!(e2 < 1e-6) || !(e1 == e1)) {
+      set_error("nnmpc_qp_set_inverse: |P Pinv - I|_max = %.3e: the supplied inverse is not usable", e2);
+      return NNMPC_EINVAL;
+    }
+  }
   h->have_inverse = true;
   return NNMPC_OK;
 }
