@@ -1142,6 +1142,7 @@ int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on) {
 int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
   if (!h || !out) return NNMPC_EINVAL;
   *out = h->stats;
+  out->asm_e1max = h->asm_e1max; out->asm_e2max = h->asm_e2max;
   {
     unsigned long long c = 0;
     hipMemcpy(&c, h->trsv_count, sizeof(c), hipMemcpyDeviceToHost);

@@ -42,8 +42,13 @@ def test_cdu_size_kkt_symmetry_permutation():
     N = pl["N"]
     x0[0] = 0.0                                            # trivial problem: u* = 0, nothing active
     lb[0], ub[0] = -1.0, 1.0
+    qp.stats(reset=True)
     out = qp.solve_batch(x0, lb, ub)
     assert (out["status"] == 0).all()
+    st = qp.stats()
+    # default method: the shared-inverse active-set pass must be what solved them (no silent fallback)
+    assert st["asm_solved"] == B and st["factorizations"] == 0
+    assert st["asm_e2max"] < 1e-9 and st["asm_e1max"] < 1e-9 * max(1.0, np.abs(tq).max())
     _kkt(P, tq, nu, N, x0, lb, ub, out, 1e-7)
     assert np.abs(out["u"][0]).max() < 1e-12 and not out["active"][0].any()
     assert out["active"].any(axis=1).sum() > B // 2          # the batch does exercise the bounds
@@ -71,3 +76,25 @@ def test_cstrs_config_10k_batch_kkt():
     ok = out["status"] == 0
     sub = {k: v[ok] for k, v in out.items()}
     _kkt(P, tq, nu, pl["N"], x0[ok], lb[ok], ub[ok], sub, 1e-7)
+
+
+def test_cdu_size_pdip_path_and_fallback_agree_with_active_set_pass():
+    """The two device paths are independent implementations (f32 MFMA Cholesky PDIP + f64 polish vs
+    f64 shared-inverse active set): same optimum, same active sets.  With asm_max_active tiny the
+    auto method must hand everything to the PDIP path and still return certified results."""
+    B = 48
+    pl, P, tq, nu, x0, lb, ub, qp = _setup("cdu", B, 23, 2.0, max_batch=128)
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    fast = qp.solve_batch(x0, lb, ub)
+    qp2 = BatchedBoxQP(P, tq, nu, max_batch=128, method="pdip")
+    slow = qp2.solve_batch(x0, lb, ub)
+    assert (fast["status"] == 0).all() and (slow["status"] == 0).all()
+    assert (slow["factorizations"] >= 1).all() and (fast["factorizations"] == 0).all()
+    assert np.abs(fast["u"] - slow["u"]).max() < 1e-7
+    assert np.array_equal(fast["active"], slow["active"])
+    qp3 = BatchedBoxQP(P, tq, nu, max_batch=128, method="auto", asm_max_active=16)
+    qp3.stats(reset=True)
+    fb = qp3.solve_batch(x0, lb, ub)
+    st = qp3.stats()
+    assert (fb["status"] == 0).all() and st["asm_solved"] < B and st["factorizations"] > 0
+    assert np.abs(fb["u"] - fast["u"]).max() < 1e-7 and np.array_equal(fb["active"], fast["active"])
