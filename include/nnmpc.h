@@ -93,6 +93,8 @@ typedef struct {
   double asm_gemm_flops;     /* algorithmic flops: 2 n^2 per running problem and round */
   double asm_lambda_ms;      /* hipEvent time of asm_lambda_k */
   double asm_update_ms;      /* hipEvent time of asm_update_k */
+  double asm_lambda_flops;   /* algorithmic fp64 flops of the multiplier systems: sum of m^3/3 + 2 m^2 */
+  double asm_lambda_bytes;   /* ... and their algorithmic bytes (gathered Pinv block + rhs/result) */
   double asm_e1max;          /* max |P Kunc + tq| of the verified inverse (nnmpc_qp_set_inverse) */
   double asm_e2max;          /* max |P Pinv - I| */
 } nnmpc_qp_stats;

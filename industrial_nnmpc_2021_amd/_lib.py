@@ -24,7 +24,8 @@ class QpStats(C.Structure):
                 ("panel_ms", C.c_double), ("diag_ms", C.c_double), ("trsv_ms", C.c_double),
                 ("total_ms", C.c_double), ("panel_flops", C.c_double), ("trsv_solves", C.c_int64), ("asm_solved", C.c_int64),
                 ("asm_rounds", C.c_int64), ("asm_gemm_launches", C.c_int64), ("asm_gemm_ms", C.c_double),
-                ("asm_gemm_flops", C.c_double), ("asm_lambda_ms", C.c_double), ("asm_update_ms", C.c_double), ("asm_e1max", C.c_double),
+                ("asm_gemm_flops", C.c_double), ("asm_lambda_ms", C.c_double), ("asm_update_ms", C.c_double), ("asm_lambda_flops", C.c_double),
+                ("asm_lambda_bytes", C.c_double), ("asm_e1max", C.c_double),
                 ("asm_e2max", C.c_double)]
 
 

@@ -56,6 +56,7 @@ struct AsmDev {
   int* binlist;                    // [ASM_NBIN][nseg] problems by active-set size (LDS size / occupancy classes)
   int* idxg;                       // [nseg][max_active] ordered active indices (asm_count_k)
   int* mg;                         // [nseg] their number
+  double* work;                    // [2] statistics: fp64 flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
   double* u_out;
@@ -126,6 +127,11 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   }
   if (tid == 0) {
     d.mg[p] = m;
+    if (m <= d.max_active && d.work) {
+      const double md = (double)m;
+      atomicAdd(&d.work[0], md * md * md / 3.0 + 2.0 * md * md);
+      atomicAdd(&d.work[1], 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md));
+    }
     if (m > d.max_active) d.state[p] = ASM_FALLBACK;
     else if (m > ASM_MLDS) d.biglist[atomicAdd(&d.counters[1], 1)] = p;
     else {

@@ -617,6 +617,7 @@ struct nnmpc_qp {
   int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg;
   int asm_pool;
   double asm_e1max, asm_e2max;
+  double* asm_work;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
   double* x0_64;        // [seg_max][ka]
   float* x0_32;
@@ -837,7 +838,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.scratch = h->asm_scratch;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   HIPCHK(hipMemsetAsync(h->asm_lam, 0, (size_t)segp * h->np * sizeof(double), s));
@@ -1013,7 +1014,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, 8);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NBIN * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_work, 2);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
@@ -1143,6 +1144,12 @@ int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
   if (!h || !out) return NNMPC_EINVAL;
   *out = h->stats;
   out->asm_e1max = h->asm_e1max; out->asm_e2max = h->asm_e2max;
+  {
+    double w[2] = {0.0, 0.0};
+    hipMemcpy(w, h->asm_work, sizeof(w), hipMemcpyDeviceToHost);
+    out->asm_lambda_flops = w[0]; out->asm_lambda_bytes = w[1];
+    if (reset) hipMemset(h->asm_work, 0, sizeof(w));
+  }
   {
     unsigned long long c = 0;
     hipMemcpy(&c, h->trsv_count, sizeof(c), hipMemcpyDeviceToHost);
