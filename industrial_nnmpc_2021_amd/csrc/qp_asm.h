@@ -26,8 +26,10 @@ namespace nnmpc {
 constexpr int ASM_MLDS = 176;      // largest active set factored in LDS (11 x 11 lower 16x16 fp64 tiles)
 constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: conflict-free MFMA operand reads)
 enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3 };   // CERT: finished and certified by the inverse-error bound
-constexpr int ASM_NBIN = 3;
-__host__ __device__ constexpr int asm_bin_cap(int b) { return b == 0 ? 96 : (b == 1 ? 128 : ASM_MLDS); }
+constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
+constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds) run the register kernel, the others the LDS-tile kernel
+constexpr int ASM_NCNT = 16;       // ints in AsmDev::counters
+__host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
 
 struct AsmDev {
   int n, np, nu, nseg;
@@ -56,7 +58,7 @@ struct AsmDev {
   int* binlist;                    // [ASM_NBIN][nseg] problems by active-set size (LDS size / occupancy classes)
   int* idxg;                       // [nseg][max_active] ordered active indices (asm_count_k)
   int* mg;                         // [nseg] their number
-  double* work;                    // [2] statistics: fp64 flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels
+  double* work;                    // [nseg][2] statistics: fp64 flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
   double* u_out;
@@ -129,13 +131,13 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
     d.mg[p] = m;
     if (m <= d.max_active && d.work) {
       const double md = (double)m;
-      atomicAdd(&d.work[0], md * md * md / 3.0 + 2.0 * md * md);
-      atomicAdd(&d.work[1], 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md));
+      d.work[2 * p] += md * md * md / 3.0 + 2.0 * md * md;             // per-problem slots: a same-address fp64
+      d.work[2 * p + 1] += 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md);   // atomic per workgroup serialises the launch
     }
     if (m > d.max_active) d.state[p] = ASM_FALLBACK;
     else if (m > ASM_MLDS) d.biglist[atomicAdd(&d.counters[1], 1)] = p;
     else {
-      const int b = m <= asm_bin_cap(0) ? 0 : (m <= asm_bin_cap(1) ? 1 : 2);
+      const int b = max((m + 15) / 16, 4) - 4;
       d.binlist[(size_t)b * d.nseg + atomicAdd(&d.counters[4 + b], 1)] = p;
     }
   }
@@ -163,8 +165,64 @@ __device__ __forceinline__ f64x4_t tile_mma_nt(const double* A, const double* B,
 }
 __device__ __forceinline__ double* asm_tile(double* T, int I, int J) { return T + ((size_t)I * (I + 1) / 2 + J) * ASM_TS; }
 
+#define ASM_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// value of lane `L` of each 16-lane row, in every lane of that row (DPP row_newbcast: VALU only, the
+// result stays in VGPRs -- 120 live v_readlane SGPR pairs per tile made the compiler spill SGPRs)
+template <int L>
+__device__ __forceinline__ double bcast16_c(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + L, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + L, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast16(double x, int l) {   // l: compile-time constant after unrolling
+  switch (l) {
+    case 0: return bcast16_c<0>(x);   case 1: return bcast16_c<1>(x);   case 2: return bcast16_c<2>(x);
+    case 3: return bcast16_c<3>(x);   case 4: return bcast16_c<4>(x);   case 5: return bcast16_c<5>(x);
+    case 6: return bcast16_c<6>(x);   case 7: return bcast16_c<7>(x);   case 8: return bcast16_c<8>(x);
+    case 9: return bcast16_c<9>(x);   case 10: return bcast16_c<10>(x); case 11: return bcast16_c<11>(x);
+    case 12: return bcast16_c<12>(x); case 13: return bcast16_c<13>(x); case 14: return bcast16_c<14>(x);
+    default: return bcast16_c<15>(x);
+  }
+}
+
+// 16 x 16 diagonal tile: Cholesky L and Y = L^-1 in one sweep of 16 column steps, no LDS traffic in
+// the chain.  Lanes 0..31 (two mirrored 16-lane rows) hold the rows of the tile, lanes 32..63 the
+// columns of Y (lane 32 + j: Y[.][j], starting from e_j): with w = x[cc] / L[cc][cc] both halves run
+// the SAME update  x[c2] -= w * L[c2][cc]  -- it is the elimination step for the first half and the
+// forward substitution L Y = I for the second.  Pivot and L[c2][cc] are wave-uniform (v_readlane from
+// lanes cc / c2), used once each, so they do not pile up in SGPRs.  16 live doubles per lane.
+// Tk: the tile in LDS (row-major, stride 17, read only); Yt receives Y (same layout).
+__device__ __forceinline__ int asm_diag16(const double* Tk, double* Yt, int lane) {
+  const int row = lane & 15;
+  const bool inv_half = lane >= 32;
+  double x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double a = Tk[row * 17 + k];
+    x[k] = inv_half ? (k == row ? 1.0 : 0.0) : a;
+  }
+  int bad = 0;
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    double dd = rdlane_d(x[cc], cc);
+    if (!(dd > 0.0)) { dd = 1.0; bad = 1; }
+    const double w = x[cc] * rsqrt(dd);                    // L[row][cc]  |  Y[cc][row]
+    x[cc] = w;
+#pragma unroll
+    for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] -= w * rdlane_d(w, c2);
+  }
+  if (lane >= 48) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = x[k];
+  }
+  return bad;
+}
+
+__device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane) { return asm_diag16(Tk, Yt, lane); }
+
 template <int BIG>
-__global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d, int bin) {
+__global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -220,48 +278,8 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d, int bin) {
   for (int K = 0; K < mb; ++K) {
     double* TKK = asm_tile(T, K, K);
     if (wave == 0) {
-      // rows on lanes (lanes 16..63 mirror 0..15); the scaled pivot column travels through a
-      // 16-double LDS line (one ds_write + broadcast ds_reads per step), no fp64 divisions
-      const int row = lane & 15;
-      double a[16], y[16], invd[16];
-      double* colb = Yt;                               // Yt is rewritten below, free until then
-#pragma unroll
-      for (int k = 0; k < 16; ++k) a[k] = TKK[row * 17 + k];
-      int bad = 0;
-#pragma unroll
-      for (int cc = 0; cc < 16; ++cc) {
-        if (lane == cc) colb[16] = a[cc];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lanes exchange through LDS: no forwarding across this point
-        double dd = colb[16];
-        if (!(dd > 0.0)) { dd = 1.0; bad = 1; }
-        const double inv = rsqrt(dd);
-        invd[cc] = inv;
-        const double lc = a[cc] * inv;
-        a[cc] = lc;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads of the previous column done before it is overwritten
-        if (lane < 16) colb[row] = lc;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int c2 = cc + 1; c2 < 16; ++c2) a[c2] -= lc * colb[c2];
-      }
-      // Y = L^-1: lane `row` computes COLUMN `row`;  L[r][k] (uniform) is read from the tile in LDS
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) TKK[row * 17 + k] = k <= row ? a[k] : 0.0;   // L_KK, strict upper zero
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double sacc = (r == row) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) sacc -= TKK[r * 17 + k] * y[k];
-        y[r] = sacc * invd[r];
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = y[k];                     // Y[k][row]
-        if (bad && lane == 0) s_bad = 1;
-      }
+      const int bad = asm_diag16_call(TKK, Yt, lane);  // Y_K = L_KK^-1 -> Yt (L_KK itself is not needed again)
+      if (bad && lane == 0) s_bad = 1;
     }
     __syncthreads();
     for (int I = K + 1 + wave; I < mb; I += 4) {       // TRSM: T(I,K) <- T(I,K) Y'
@@ -282,12 +300,11 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d, int bin) {
           for (int r = 0; r < 4; ++r) TIJ[((lane >> 4) + 4 * r) * 17 + (lane & 15)] -= acc[r];
         }
     }
-    // keep Y_K for the solves: its transpose goes into the (now unused) strict upper part of T(K,K),
-    // its diagonal is 1 / L_KK's diagonal
+    // keep Y_K for the solves: its transpose goes into the upper part of T(K,K) (diagonal included)
     if (wave == 0 && lane < 16) {
       const int row = lane;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) if (k > row) TKK[row * 17 + k] = Yt[k * 17 + row];   // Y[k][row], k > row
+      for (int k = 0; k < 16; ++k) if (k >= row) TKK[row * 17 + k] = Yt[k * 17 + row];   // Y[k][row], k >= row
     }
     __syncthreads();
   }
@@ -304,9 +321,9 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d, int bin) {
       }
       t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
       t = rA[16 * K + i] - t;                            // all 64 lanes hold t_i (i = lane & 15)
-      // y_K = Y_K t,  Y_K[i][k] (k < i) stored at TKK[k][i], Y_K[i][i] = 1 / TKK[i][i]
+      // y_K = Y_K t,  Y_K[i][k] (k <= i) stored at TKK[k][i]
       const double* TKK = asm_tile(T, K, K);
-      double yv = t / TKK[i * 17 + i];
+      double yv = t * TKK[i * 17 + i];
 #pragma unroll
       for (int k = 0; k < 16; ++k) { const double tk = __shfl(t, k); if (k < i) yv += TKK[k * 17 + i] * tk; }
       if (lane < 16) rA[16 * K + i] = yv;
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d, int bin) {
       t = rA[16 * K + i] - t;
       // lam_K = Y_K' t:  lam_i = sum_{k >= i} Y_K[k][i] t_k,  Y_K[k][i] (k > i) stored at TKK[i][k]
       const double* TKK = asm_tile(T, K, K);
-      double lv = t / TKK[i * 17 + i];
+      double lv = t * TKK[i * 17 + i];
 #pragma unroll
       for (int k = 0; k < 16; ++k) { const double tk = __shfl(t, k); if (k > i) lv += TKK[i * 17 + k] * tk; }
       if (lane < 16) rA[16 * K + i] = lv;
@@ -333,6 +350,237 @@ __global__ __launch_bounds__(256) void asm_lambda_tile_k(AsmDev d, int bin) {
   __syncthreads();
   for (int i = tid; i < m; i += 256) d.lam[o + idx[i]] = rA[i];     // the rest of the row is zero (asm_update_k)
   }
+}
+
+// ---- register-resident version, one instantiation per number MB of 16-blocks: ONE WAVE PER PROBLEM,
+// no workgroup barriers, straight-line code.
+// Accumulator t(I,J) of the wave holds the TRANSPOSE of tile (I,J) (I >= J) in the MFMA C/D layout
+// (reg r of lane (li, lq): element [li][lq + 4r] of the tile).  The C/D registers of a transposed tile
+// are exactly the A/B operand fragments of the tile itself (lane (li, lq), step s: [li][4s + lq]), so
+//   TRSM      L(I,K)' = Y_K S(I,K)'            A = fragments of Y_K (LDS),  B = t(I,K)
+//   trailing  S(I,J)' -= L(J,K) L(I,K)'         A = -t(J,K),                 B = t(I,K)
+// run MFMA register to register; LDS only transposes the diagonal tile (C layout -> rows on lanes)
+// and its inverse (columns on lanes -> fragments): two fences per block column.  Both substitutions
+// stay in registers: sums over a tile row are DPP reductions inside the 16-lane rows, sums over the
+// four lane rows use v_permlane16/32_swap.
+// The 512 registers of a wave hold 32 tiles next to the working set; for MB = 8, 9 the strictly lower
+// tiles of the first NL = 2 block columns -- touched by one TRSM, one pass as operands and the backward
+// substitution only -- live in LDS instead (C layout, 2 KB each).
+__host__ __device__ constexpr int asm_nl(int mb) { return mb <= 7 ? 0 : 2; }
+__host__ __device__ constexpr int asm_nlt(int mb) { return asm_nl(mb) == 0 ? 0 : (asm_nl(mb) == 1 ? mb - 1 : 2 * mb - 3); }
+__host__ __device__ constexpr int asm_rw(int mb) { return 2 * ASM_TS + 2 * mb * 16 + asm_nlt(mb) * 256; }   // doubles of LDS per wave
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a lane row, result in every lane of the row
+__device__ __forceinline__ double rowsum16(double x) {
+  x += dpp_mov_d<0xB1>(x);        // quad_perm [1,0,3,2]
+  x += dpp_mov_d<0x4E>(x);        // quad_perm [2,3,0,1]
+  x += dpp_mov_d<0x141>(x);       // row_half_mirror
+  x += dpp_mov_d<0x140>(x);       // row_mirror
+  return x;
+}
+// sum over the four lane rows (lanes l, l^16, l^32, l^48), result in all of them
+__device__ __forceinline__ double xsum4(double x) {
+  {
+    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  {
+    const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  return x;
+}
+
+__host__ __device__ constexpr int asm_tix(int I, int J) { return I * (I + 1) / 2 + J; }
+
+template <int MB>
+__device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg) {
+  constexpr int NL = asm_nl(MB);
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  double* dt = sm + (size_t)wave * asm_rw(MB);             // diagonal tile, row-major stride 17
+  double* Yt = dt + ASM_TS;                                // its inverse factor
+  double* ys = Yt + ASM_TS;                                // y (forward result), [MB][16]
+  double* rv = ys + MB * 16;                               // right-hand side, [MB][16]
+  double* lt = rv + MB * 16 + lane;                        // LDS-resident tiles: slot * 256 + r * 64 (+ lane)
+  auto slot = [](int I, int J) { return J == 0 ? I - 1 : MB - 1 + I - 2; };   // tile (I,J), J < NL, I > J
+  const int nitem = d.counters[4 + bin];
+  const int it = wg * 4 + wave;
+  if (it >= nitem) return;
+  const int p = __builtin_amdgcn_readfirstlane(d.binlist[(size_t)bin * d.nseg + it]);
+  const size_t o = (size_t)p * d.np;
+  const unsigned char* st = d.st + (size_t)p * d.n;
+  const int* idx = d.idxg + (size_t)p * d.max_active;
+  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
+  if (m <= 0) return;
+  // ---- rhs -> LDS (read back block by block: registers are the scarce resource here)
+  for (int i = lane; i < MB * 16; i += 64) {
+    const int a = idx[min(i, m - 1)], k = a % d.nu;
+    const double v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+    rv[i] = i < m ? v : 0.0;
+  }
+  // ---- gather: t(I,J)[r] = -S[16 I + li][16 J + lq + 4 r], read as Pinv[row of (J, lq, r)][col of (I, li)].
+  // The not yet factored tiles hold MINUS the Schur complement, so the trailing update is a plain
+  // accumulation (fp64 MFMA has no negate modifier; a VALU negation would cost a pass over the operands).
+  f64x4_t C[MB * (MB + 1) / 2];
+  {
+    int gcol[MB];                                          // Pinv index of active bound 16 I + li
+#pragma unroll
+    for (int I = 0; I < MB; ++I) gcol[I] = idx[min(16 * I + li, m - 1)];
+#pragma unroll
+    for (int J = 0; J < MB; ++J) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gj = 16 * J + lq + 4 * r;
+        const double* Hr = d.H + (size_t)idx[min(gj, m - 1)] * d.np;
+#pragma unroll
+        for (int I = J; I < MB; ++I) {                     // unconditional (clamped) loads, then select
+          const int gi = 16 * I + li;
+#ifdef DBG_NO_GATHER
+          const double v = 0.001 * (double)(gcol[I] & 7);
+#else
+          const double v = Hr[gcol[I]];
+#endif
+          const double e = (gi < m && gj < m) ? -v : (gi == gj ? -1.0 : 0.0);
+          if (J < NL && I > J) lt[slot(I, J) * 256 + r * 64] = e;
+          else C[asm_tix(I, J)][r] = e;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double ps[MB];                                           // lane-local partial sums of  sum_J L(I,J) y_J
+#pragma unroll
+  for (int I = 0; I < MB; ++I) ps[I] = 0.0;
+  int bad = 0;
+  // ---- blocked Cholesky (right-looking) with the forward substitution riding along
+#pragma unroll
+  for (int K = 0; K < MB; ++K) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dt[li * 17 + lq + 4 * r] = -C[asm_tix(K, K)][r];
+    ASM_FENCE();
+#ifndef DBG_NO_DIAG
+    bad |= asm_diag16(dt, Yt, lane);
+#endif
+    ASM_FENCE();
+    __builtin_amdgcn_sched_barrier(0);
+    double yf[4];                                          // fragments of -Y_K
+    f64x4_t Yc;                                            // Y_K' in C layout: [li][lq + 4r] of Y' = Y[lq + 4r][li]
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { yf[s4] = -Yt[li * 17 + 4 * s4 + lq]; Yc[s4] = Yt[(lq + 4 * s4) * 17 + li]; }
+    C[asm_tix(K, K)] = Yc;
+    // y_K = Y_K (r_K - sum_{J<K} L(K,J) y_J)
+    const double tK = rv[16 * K + li] - (K ? xsum4(ps[K]) : 0.0);
+    double yq[4];                                          // y_K[lq + 4r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) yq[r] = rowsum16(Yc[r] * tK);
+    if (li == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ys[16 * K + lq + 4 * r] = yq[r];
+    }
+    f64x4_t P[MB];                                         // the panel of an LDS-resident column (K < NL)
+#pragma unroll
+    for (int I = K + 1; I < MB; ++I) {                     // TRSM: L(I,K)' = Y_K S(I,K)'
+      f64x4_t b;
+      if (K < NL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = lt[slot(I, K) * 256 + r * 64];
+      } else {
+        b = C[asm_tix(I, K)];
+      }
+      f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yf[s4], b[s4], acc, 0, 0, 0);
+      if (K < NL) {
+        P[I] = acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lt[slot(I, K) * 256 + r * 64] = acc[r];
+      } else {
+        C[asm_tix(I, K)] = acc;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ps[I] += acc[r] * yq[r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef DBG_NO_TRAIL
+#pragma unroll
+    for (int J = K + 1; J < MB; ++J) {                     // trailing update, column by column (column K+1 first)
+#pragma unroll
+      for (int I = J; I < MB; ++I) {
+        const bool in_lds = J < NL && I > J;
+        f64x4_t acc;
+        if (in_lds) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = lt[slot(I, J) * 256 + r * 64];
+        } else {
+          acc = C[asm_tix(I, J)];
+        }
+        const f64x4_t a = K < NL ? P[J] : C[asm_tix(J, K)], b = K < NL ? P[I] : C[asm_tix(I, K)];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc, 0, 0, 0);
+        if (in_lds) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lt[slot(I, J) * 256 + r * 64] = acc[r];
+        } else {
+          C[asm_tix(I, J)] = acc;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+  }
+  if (bad) { if (lane == 0) d.state[p] = ASM_FALLBACK; return; }
+  ASM_FENCE();
+  // ---- backward substitution  L' lam = y
+  double lam[MB];
+#pragma unroll
+  for (int K = MB - 1; K >= 0; --K) {
+    double part = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double tt = ys[16 * K + lq + 4 * r];
+      if (K < MB - 1) {
+        double s4 = 0.0;                                   // (sum_I L(I,K)' lam_I)[lq + 4r], summed over li
+#pragma unroll
+        for (int I = K + 1; I < MB; ++I) s4 += (K < NL ? lt[slot(I, K) * 256 + r * 64] : C[asm_tix(I, K)][r]) * lam[I];
+        tt -= rowsum16(s4);
+      }
+      part += C[asm_tix(K, K)][r] * tt;                    // Y_K[lq + 4r][li] tt[lq + 4r]
+    }
+    lam[K] = xsum4(part);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int I = 0; I < MB; ++I) {
+    const int i = 16 * I + li;
+    if (lq == 0 && i < m) d.lam[o + idx[i]] = lam[I];
+  }
+}
+
+// All register-resident size classes in ONE launch (their workgroups are independent; separate
+// launches would serialise six tails): workgroup w walks the classes from the largest down and takes
+// four problems of the class its index falls into.  Grid: sum_b ceil(count_b / 4) <= nrun / 4 + ASM_NREG.
+constexpr int ASM_REG_LDS = 4 * asm_rw(ASM_NREG + 3) * 8;  // bytes of dynamic LDS (largest class)
+__global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
+  int w = blockIdx.x;
+#define ASM_REG_CLASS(B)                                                   \
+  {                                                                        \
+    const int nb = (d.counters[4 + B] + 3) >> 2;                           \
+    if (w < nb) { asm_lambda_reg<B + 4>(d, B, w); return; }                \
+    w -= nb;                                                               \
+  }
+  ASM_REG_CLASS(5) ASM_REG_CLASS(4) ASM_REG_CLASS(3) ASM_REG_CLASS(2) ASM_REG_CLASS(1) ASM_REG_CLASS(0)
+#undef ASM_REG_CLASS
+  static_assert(ASM_NREG == 6, "one ASM_REG_CLASS line per register-resident size class");
 }
 
 // x from the GEMM result, fp64 KKT tests, next active set.  A problem whose set no longer changes

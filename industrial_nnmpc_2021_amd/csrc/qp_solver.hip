@@ -626,6 +626,8 @@ struct nnmpc_qp {
   double *lb_d, *ub_d;  // [seg_max][nu] staging for host inputs
   double* in_stage;     // [seg_max][n_aug]
   hipStream_t stream;
+  hipStream_t stream2 = nullptr;     // side stream of the active-set rounds (large-set kernels)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool profiling;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used;
@@ -848,17 +850,24 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   int rounds = 0;
   int nrun = nprob;
   for (; rounds < a.max_rounds + 1; ++rounds) {
-    HIPCHK(hipMemsetAsync(h->asm_counters, 0, 8 * sizeof(int), s));
+    HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
     {
       EvScope es(h, 4, 0.0);
       hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
-      // one launch per size class: the LDS footprint (hence the workgroups per CU) follows the class
-      for (int b = 0; b < ASM_NBIN; ++b) {
+      // size classes 0..ASM_NREG-1 (<= 144 bounds): one wave per problem, S in registers, one launch.  The
+      // few larger sets (one workgroup per problem, tiles in LDS or in an L2 slab) are long latency chains
+      // on a handful of CUs: they run beside it on the side stream.
+      HIPCHK(hipEventRecord(h->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+      for (int b = ASM_NREG; b < ASM_NBIN; ++b) {
         const int mbc = asm_bin_cap(b) / 16;
         const int lds = (asm_bin_cap(b) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
-        hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nrun), dim3(256), lds, s, a, b);
+        hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nrun), dim3(256), lds, h->stream2, a, b);
       }
-      hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(h->asm_pool), dim3(256), lds_big, s, a, 0);
+      hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(h->asm_pool), dim3(256), lds_big, h->stream2, a, 0);
+      HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+      hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nrun + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, s, a);
+      HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     {
       EvScope es(h, 5, 0.0);   // flops are added after the round's counters are read back
@@ -976,6 +985,16 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->have_kunc = Kunc != nullptr;
   if ((size_t)(h->np + 5 * h->NB) * 4 > 96 * 1024) { set_error("n too large for the LDS-resident solve vector"); delete h; return NNMPC_EINVAL; }
   if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return NNMPC_EHIP; }
+  if (hipStreamCreate(&h->stream2) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    set_error("hipStreamCreate / hipEventCreate failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP;
+  }
+  {
+    hipError_t e = hipFuncSetAttribute((const void*)asm_lambda_tile_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (ASM_MLDS + ASM_TS + (ASM_MLDS / 16) * (ASM_MLDS / 16 + 1) / 2 * ASM_TS) * 8);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
+  }
   if (set_lds_attrs<128>() != 0 || set_lds_attrs<64>() != 0) {
     set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP;
   }
@@ -1012,9 +1031,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->asm_pool = 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
-  A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, 8);
+  A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NBIN * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_work, 2);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_work, 2 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
@@ -1081,6 +1100,9 @@ int nnmpc_qp_destroy(nnmpc_qp* h) {
   hipDeviceSynchronize();
   for (void* p : h->allocs) hipFree(p);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return NNMPC_OK;
@@ -1145,10 +1167,12 @@ int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
   *out = h->stats;
   out->asm_e1max = h->asm_e1max; out->asm_e2max = h->asm_e2max;
   {
-    double w[2] = {0.0, 0.0};
-    hipMemcpy(w, h->asm_work, sizeof(w), hipMemcpyDeviceToHost);
-    out->asm_lambda_flops = w[0]; out->asm_lambda_bytes = w[1];
-    if (reset) hipMemset(h->asm_work, 0, sizeof(w));
+    std::vector<double> w(2 * (size_t)h->seg_max, 0.0);
+    hipMemcpy(w.data(), h->asm_work, w.size() * sizeof(double), hipMemcpyDeviceToHost);
+    double f = 0.0, b = 0.0;
+    for (size_t i = 0; i < w.size(); i += 2) { f += w[i]; b += w[i + 1]; }
+    out->asm_lambda_flops = f; out->asm_lambda_bytes = b;
+    if (reset) hipMemset(h->asm_work, 0, w.size() * sizeof(double));
   }
   {
     unsigned long long c = 0;

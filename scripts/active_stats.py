@@ -18,3 +18,7 @@ print("last stage with any active, quantiles:", np.quantile([(np.flatnonzero(r).
 for kb in (16, 64):
     blk = st.reshape(B // 64, 64, n // kb, kb).any(axis=(1, 3))      # (rowblocks, kblocks)
     print("kblock", kb, "fraction of (64-row block, k-block) pairs that are non-zero:", blk.mean())
+m = st.sum(1)
+print("|A| at the solution: quantiles 1/10/50/90/99/100 %:", np.quantile(m, [0.01, 0.1, 0.5, 0.9, 0.99, 1.0]))
+edges = [0, 64, 80, 96, 112, 128, 144, 160, 176, 192, 256, 10000]
+print("histogram over", edges, ":", np.histogram(m, edges)[0] / B)

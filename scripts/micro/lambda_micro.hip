@@ -1,0 +1,94 @@
+// Micro-benchmark of the multiplier-system kernels (qp_asm.h) on synthetic sets of a fixed size.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I industrial_nnmpc_2021_amd/csrc scripts/micro/lambda_micro.hip -o gpurun_out/lambda_micro
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <random>
+#include <algorithm>
+#include "qp_asm.h"
+using namespace nnmpc;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+  const int m = argc > 1 ? atoi(argv[1]) : 112;
+  const int nseg = argc > 2 ? atoi(argv[2]) : 14336;
+  const int variant = argc > 3 ? atoi(argv[3]) : 0;      // 0 tile kernel, 1 register kernel
+  const int n = 512, np = 512, nu = 32, win = 416, max_active = 768;
+  std::mt19937_64 rng(1);
+  std::normal_distribution<double> g(0.0, 1.0);
+  std::vector<double> G((size_t)n * n), H((size_t)n * n);
+  for (auto& v : G) v = g(rng) / sqrt((double)n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = i == j ? 0.5 : 0.0;
+      for (int k = 0; k < n; ++k) s += G[(size_t)i * n + k] * G[(size_t)j * n + k];
+      H[(size_t)i * n + j] = H[(size_t)j * n + i] = s;
+    }
+  std::vector<int> idx((size_t)nseg * max_active, 0), mg(nseg, m), list(nseg);
+  std::vector<unsigned char> st((size_t)nseg * n, 0);
+  std::vector<double> xunc((size_t)nseg * np), lb(nseg * nu, -1.0), ub(nseg * nu, 0.25);
+  for (auto& v : xunc) v = g(rng);
+  std::vector<int> perm(win);
+  for (int p = 0; p < nseg; ++p) {
+    for (int i = 0; i < win; ++i) perm[i] = i;
+    std::shuffle(perm.begin(), perm.end(), rng);
+    std::sort(perm.begin(), perm.begin() + m);
+    for (int i = 0; i < m; ++i) { idx[(size_t)p * max_active + i] = perm[i]; st[(size_t)p * n + perm[i]] = 1 + (perm[i] & 1); }
+    list[p] = p;
+  }
+  AsmDev d{};
+  d.n = n; d.np = np; d.nu = nu; d.nseg = nseg; d.max_active = max_active;
+  double *dH, *dlb, *dub, *dxu, *dlam; unsigned char* dst; int *dstate, *dcnt, *dbin, *didx, *dmg;
+  CK(hipMalloc(&dH, H.size() * 8)); CK(hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dlb, lb.size() * 8)); CK(hipMemcpy(dlb, lb.data(), lb.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dub, ub.size() * 8)); CK(hipMemcpy(dub, ub.data(), ub.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dxu, xunc.size() * 8)); CK(hipMemcpy(dxu, xunc.data(), xunc.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dlam, xunc.size() * 8)); CK(hipMemset(dlam, 0, xunc.size() * 8));
+  CK(hipMalloc(&dst, st.size())); CK(hipMemcpy(dst, st.data(), st.size(), hipMemcpyHostToDevice));
+  CK(hipMalloc(&dstate, nseg * 4)); CK(hipMemset(dstate, 0, nseg * 4));
+  int bin = max((m + 15) / 16, 4) - 4; if (bin >= ASM_NBIN) bin = ASM_NBIN - 1;
+  int cnt[16] = {0}; cnt[4 + bin] = nseg;
+  CK(hipMalloc(&dcnt, sizeof cnt)); CK(hipMemcpy(dcnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dbin, (size_t)ASM_NBIN * nseg * 4));
+  for (int b = 0; b < ASM_NBIN; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&didx, idx.size() * 4)); CK(hipMemcpy(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dmg, nseg * 4)); CK(hipMemcpy(dmg, mg.data(), nseg * 4, hipMemcpyHostToDevice));
+  d.H = dH; d.lb = dlb; d.ub = dub; d.xunc = dxu; d.lam = dlam; d.st = dst; d.state = dstate; d.counters = dcnt;
+  d.binlist = dbin; d.idxg = didx; d.mg = dmg;
+  const int mbc = asm_bin_cap(bin) / 16;
+  const int lds_tile = (asm_bin_cap(bin) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
+  CK(hipFuncSetAttribute((const void*)asm_lambda_tile_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (ASM_MLDS + ASM_TS + 66 * ASM_TS) * 8));
+  CK(hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 6; ++rep) {
+    CK(hipEventRecord(e0, 0));
+    if (variant == 0) hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nseg), dim3(256), lds_tile, 0, d, bin);
+    else {
+      hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, 0, d);
+    }
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) best = std::min(best, ms);
+  }
+  CK(hipGetLastError());
+  // check two problems: residual of S lam = r
+  std::vector<double> lam((size_t)2 * np);
+  std::vector<int> state(nseg);
+  CK(hipMemcpy(state.data(), dstate, nseg * 4, hipMemcpyDeviceToHost));
+  int nfb = 0; for (int s : state) nfb += s != 0;
+  double worst = 0.0;
+  for (int pp = 0; pp < 2; ++pp) {
+    const int p = pp == 0 ? 0 : nseg - 1;
+    CK(hipMemcpy(lam.data(), dlam + (size_t)p * np, np * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m; ++i) {
+      const int a = idx[(size_t)p * max_active + i];
+      double r = xunc[(size_t)p * np + a] - (st[(size_t)p * n + a] == 1 ? 0.25 : -1.0);
+      for (int j = 0; j < m; ++j) { const int b2 = idx[(size_t)p * max_active + j]; r -= H[(size_t)a * n + b2] * lam[b2]; }
+      worst = std::max(worst, fabs(r));
+    }
+  }
+  printf("variant %d m %d nseg %d: %.3f ms  (%.2f problems/us)  max residual %.2e  fallback %d\n", variant, m, nseg, best, nseg / (best * 1e3), worst, nfb);
+  return 0;
+}
