@@ -52,12 +52,15 @@ struct AsmDev {
   const unsigned char* guess;      // [nseg][n] caller's active-set estimate or NULL
   int* state;                      // [nseg] ASM_RUN / DONE / FALLBACK
   int* rounds;                     // [nseg]
-  int* counters;                   // [0] still running, [1] big-set list length, [3] largest active variable
+  int* counters;                   // [0] still running, [1] big-set list length, [2] rows handed out, [3] largest active variable
                                    // index of this round (GEMM k-range), [4 + b] length of size-bin list b
   int* biglist;                    // [nseg] problems whose set does not fit LDS
   int* binlist;                    // [ASM_NBIN][nseg] problems by active-set size (LDS size / occupancy classes)
   int* idxg;                       // [nseg][max_active] ordered active indices (asm_count_k)
   int* mg;                         // [nseg] their number
+  int* row;                        // [nseg] row of lam / xh this round: the running problems are packed into rows
+                                   // 0..nrun-1 (counters[2]), so the GEMM only covers those
+  double* qinf;                    // [nseg] max |q| (for the certificate)
   double* work;                    // [nseg][2] statistics: fp64 flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
@@ -73,6 +76,7 @@ __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1)
 // x_unc -> first active-set estimate: every bound the unconstrained minimiser violates.
 __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
   __shared__ int cnt[4];
+  __shared__ double qm[4];
   const int p = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)p * d.np;
   if (p >= d.nseg) {                 // padding rows of the GEMM operands: never active
@@ -80,9 +84,11 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     return;
   }
   int c = 0;
+  double qi = 0.0;
   for (int r = tid; r < d.n; r += 256) {
     const int k = r % d.nu;
     const double x = d.xunc[o + r];
+    qi = fmax(qi, fabs(d.q64[o + r]));
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     int s = x > ub ? 1 : (x < lb ? 2 : 0);
     if (d.guess) { s = d.guess[(size_t)p * d.n + r]; if (s > 2) s = 0; }
@@ -91,20 +97,20 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     c += s != 0;
   }
   for (int r = d.n + tid; r < d.np; r += 256) d.x[o + r] = 0.0;
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-  if ((tid & 63) == 0) cnt[tid >> 6] = c;
+  for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); qi = fmax(qi, __shfl_xor(qi, off)); }
+  if ((tid & 63) == 0) { cnt[tid >> 6] = c; qm[tid >> 6] = qi; }
   __syncthreads();
   if (tid == 0) {
     const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     d.rounds[p] = 0;
+    d.qinf[p] = fmax(fmax(qm[0], qm[1]), fmax(qm[2], qm[3]));
     // empty set: x = x_unc; done if that is feasible, which the first update round decides when the
     // set came from a caller's guess
     d.state[p] = (tot == 0 && !d.guess) ? ASM_DONE : ASM_RUN;
   }
 }
 
-// Round stage 0: ordered list of the active indices of every running problem, its length, the
-// size class (which fixes the LDS footprint, hence the occupancy, of the factorisation kernel).
+// Round stage 0a: ordered list of the active indices of every running problem and its length.
 __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   __shared__ int wsum[4];
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,21 +131,83 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
     int* idx = d.idxg + (size_t)p * d.max_active;
     int k = base;
     for (int r = r0; r < r1; ++r) if (st[r]) idx[k++] = r;
-    if (k == m && c > 0) atomicMax(&d.counters[3], r1 > r0 ? idx[m - 1] : 0);   // thread holding the last index
   }
   if (tid == 0) {
     d.mg[p] = m;
     if (m <= d.max_active && d.work) {
       const double md = (double)m;
-      d.work[2 * p] += md * md * md / 3.0 + 2.0 * md * md;             // per-problem slots: a same-address fp64
-      d.work[2 * p + 1] += 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md);   // atomic per workgroup serialises the launch
+      d.work[2 * p] += md * md * md / 3.0 + 2.0 * md * md;             // per-problem slots: same-address atomics
+      d.work[2 * p + 1] += 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md);   // (one per workgroup) serialise the launch
     }
     if (m > d.max_active) d.state[p] = ASM_FALLBACK;
-    else if (m > ASM_MLDS) d.biglist[atomicAdd(&d.counters[1], 1)] = p;
+  }
+}
+
+// Round stage 0b (one workgroup): the running problems get the rows 0..nrun-1 of LAM / XH (the GEMM
+// covers only those) and a place in the list of their size class -- exclusive scans over the
+// problems instead of one same-address atomic per problem, which cost more than the factorisations'
+// launch.  counters: [0] = [2] = nrun, [1] sets too large for LDS, [3] largest active variable index,
+// [4 + b] length of size-class list b.
+__global__ __launch_bounds__(1024) void asm_bins_k(AsmDev d) {
+  constexpr int NC = 2 + ASM_NBIN;                           // rows, big list, size classes
+  __shared__ int wtot[NC][16];
+  __shared__ int kred[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (d.nseg + 1023) / 1024;
+  const int p0 = min(d.nseg, tid * per), p1 = min(d.nseg, p0 + per);
+  int c[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) c[i] = 0;
+  int kmax = 0;
+  for (int p = p0; p < p1; ++p) {
+    if (d.state[p] != ASM_RUN) continue;
+    const int m = d.mg[p];
+    c[0] += 1;
+    if (m > ASM_MLDS) c[1] += 1;
     else {
       const int b = max((m + 15) / 16, 4) - 4;
-      d.binlist[(size_t)b * d.nseg + atomicAdd(&d.counters[4 + b], 1)] = p;
+#pragma unroll
+      for (int i = 0; i < ASM_NBIN; ++i) c[2 + i] += (i == b);
     }
+    if (m > 0) kmax = max(kmax, d.idxg[(size_t)p * d.max_active + m - 1]);
+  }
+  int base[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    int inc = c[i];
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    if (lane == 63) wtot[i][wave] = inc;
+    base[i] = inc - c[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+  if (lane == 0) kred[wave] = kmax;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    for (int w = 0; w < wave; ++w) base[i] += wtot[i][w];
+  for (int p = p0; p < p1; ++p) {
+    if (d.state[p] != ASM_RUN) continue;
+    const int m = d.mg[p];
+    d.row[p] = base[0]++;
+    if (m > ASM_MLDS) d.biglist[base[1]++] = p;
+    else {
+      const int b = max((m + 15) / 16, 4) - 4;
+#pragma unroll
+      for (int i = 0; i < ASM_NBIN; ++i)
+        if (i == b) d.binlist[(size_t)i * d.nseg + base[2 + i]++] = p;
+    }
+  }
+  if (tid < NC) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wtot[tid][w];
+    if (tid == 0) { d.counters[0] = t; d.counters[2] = t; }
+    else if (tid == 1) d.counters[1] = t;
+    else d.counters[4 + tid - 2] = t;
+  }
+  if (tid == 32) {
+    int k = 0;
+    for (int w = 0; w < 16; ++w) k = max(k, kred[w]);
+    d.counters[3] = k;
   }
 }
 
@@ -348,7 +416,10 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
     }
   }
   __syncthreads();
-  for (int i = tid; i < m; i += 256) d.lam[o + idx[i]] = rA[i];     // the rest of the row is zero (asm_update_k)
+  {
+    double* lrow = d.lam + (size_t)d.row[p] * d.np;
+    for (int i = tid; i < m; i += 256) lrow[idx[i]] = rA[i];        // the rest of the row is zero (asm_update_k)
+  }
   }
 }
 
@@ -559,10 +630,11 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
     lam[K] = xsum4(part);
     __builtin_amdgcn_sched_barrier(0);
   }
+  double* lrow = d.lam + (size_t)d.row[p] * d.np;
 #pragma unroll
   for (int I = 0; I < MB; ++I) {
     const int i = 16 * I + li;
-    if (lq == 0 && i < m) d.lam[o + idx[i]] = lam[I];
+    if (lq == 0 && i < m) lrow[idx[i]] = lam[I];
   }
 }
 
@@ -595,24 +667,21 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
   __shared__ double red[12];
   const int p = blockIdx.x, tid = threadIdx.x;
   if (d.state[p] != ASM_RUN) return;
-  const size_t o = (size_t)p * d.np;
+  const size_t o = (size_t)p * d.np, orow = (size_t)d.row[p] * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
   int chg = 0;
-  double l1 = 0.0, lmin = 1e300, qinf = 0.0;
+  double l1 = 0.0, lmin = 1e300;
   for (int r = tid; r < d.n; r += 256) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     const int s = st[r];
-    qinf = fmax(qinf, fabs(d.q64[o + r]));
     if (s == 0) {
-      const double x = d.xunc[o + r] - d.xh[o + r];
-      d.x[o + r] = x;
+      const double x = d.xunc[o + r] - d.xh[orow + r];
       if (x > ub + d.bound_tol) { st[r] = 1; ++chg; }
       else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
     } else {
-      const double l = d.lam[o + r];
-      d.lam[o + r] = 0.0;                                    // keep the LAM rows zero outside the next set
-      d.x[o + r] = s == 1 ? ub : lb;
+      const double l = d.lam[orow + r];
+      d.lam[orow + r] = 0.0;                                 // the LAM rows stay zero outside the sets in flight
       l1 += fabs(l); lmin = fmin(lmin, fabs(l));
       if ((s == 1 && l <= 0.0) || (s == 2 && l >= 0.0)) { st[r] = 0; ++chg; }   // keep iff multiplier > 0
     }
@@ -622,32 +691,32 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
   for (int off = 32; off > 0; off >>= 1) {
     chg += __shfl_xor(chg, off);
     l1 += __shfl_xor(l1, off); x1 += __shfl_xor(x1, off);
-    lmin = fmin(lmin, __shfl_xor(lmin, off)); qinf = fmax(qinf, __shfl_xor(qinf, off));
+    lmin = fmin(lmin, __shfl_xor(lmin, off));
   }
   if ((tid & 63) == 0) {
     const int w = tid >> 6;
     cnt[w] = chg; red[w] = l1; red[4 + w] = x1; red[8 + w] = lmin;
   }
   __syncthreads();
-  if ((tid & 63) == 0) cnt[tid >> 6] += 0;
-  __syncthreads();
   const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-  // qinf needs its own slot: reuse via a second pass
-  __shared__ double qred[4];
-  if ((tid & 63) == 0) qred[tid >> 6] = qinf;
-  __syncthreads();
+  if (tot == 0) {                                            // finished: only now x is written out
+    for (int r = tid; r < d.n; r += 256) {
+      const int k = r % d.nu, s = st[r];
+      d.x[o + r] = s == 0 ? d.xunc[o + r] - d.xh[orow + r]
+                          : (s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+    }
+  }
   if (tid == 0) {
     const int rd = d.rounds[p] + 1;
     d.rounds[p] = rd;
     if (tot == 0) {
       const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
       const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
-      const double QI = fmax(fmax(qred[0], qred[1]), fmax(qred[2], qred[3]));
+      const double QI = d.qinf[p];
       const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
       const bool sure = bnd <= d.stat_tol * fmax(d.pscale, QI) && LM > bnd;
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
     } else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
-    else atomicAdd(&d.counters[0], 1);
   }
 }
 

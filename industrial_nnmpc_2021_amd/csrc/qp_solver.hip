@@ -614,7 +614,8 @@ struct nnmpc_qp {
   double* Kunc64;   // np x ka
   double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch;
   unsigned char* asm_st;
-  int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg;
+  int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row;
+  double* asm_qinf;
   int asm_pool;
   double asm_e1max, asm_e2max;
   double* asm_work;
@@ -840,51 +841,59 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.qinf = h->asm_qinf; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   HIPCHK(hipMemsetAsync(h->asm_lam, 0, (size_t)segp * h->np * sizeof(double), s));
   hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
   const int lds_big = (a.max_active + ASM_TS) * 8;
-  int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cnt[ASM_NCNT] = {0};
   int rounds = 0;
-  int nrun = nprob;
   for (; rounds < a.max_rounds + 1; ++rounds) {
-    HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
+    {
+      EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
+      hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(asm_bins_k, dim3(1), dim3(1024), 0, s, a);
+    }
+    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int nrun = cnt[0];
+    if (nrun == 0) break;
+    h->stats.asm_rounds += 1;
     {
       EvScope es(h, 4, 0.0);
-      hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
       // size classes 0..ASM_NREG-1 (<= 144 bounds): one wave per problem, S in registers, one launch.  The
       // few larger sets (one workgroup per problem, tiles in LDS or in an L2 slab) are long latency chains
       // on a handful of CUs: they run beside it on the side stream.
-      HIPCHK(hipEventRecord(h->ev_fork, s));
-      HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-      for (int b = ASM_NREG; b < ASM_NBIN; ++b) {
-        const int mbc = asm_bin_cap(b) / 16;
-        const int lds = (asm_bin_cap(b) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
-        hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nrun), dim3(256), lds, h->stream2, a, b);
+      int nbig = cnt[1], nreg_wg = 0;
+      for (int b = ASM_NREG; b < ASM_NBIN; ++b) nbig += cnt[4 + b];
+      for (int b = 0; b < ASM_NREG; ++b) nreg_wg += (cnt[4 + b] + 3) / 4;
+      if (nbig) {
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        for (int b = ASM_NREG; b < ASM_NBIN; ++b) {
+          if (cnt[4 + b] == 0) continue;
+          const int mbc = asm_bin_cap(b) / 16;
+          const int lds = (asm_bin_cap(b) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
+          hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(cnt[4 + b]), dim3(256), lds, h->stream2, a, b);
+        }
+        if (cnt[1]) hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream2, a, 0);
+        HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       }
-      hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(h->asm_pool), dim3(256), lds_big, h->stream2, a, 0);
-      HIPCHK(hipEventRecord(h->ev_join, h->stream2));
-      hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nrun + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, s, a);
-      HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+      if (nreg_wg) hipLaunchKernelGGL(asm_lambda_reg_k, dim3(nreg_wg), dim3(256), ASM_REG_LDS, s, a);
+      if (nbig) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     {
-      EvScope es(h, 5, 0.0);   // flops are added after the round's counters are read back
-      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, segp, h->np, h->np, h->asm_state, ASM_RUN,
+      // the running problems sit in rows 0..nrun-1 of LAM (asm_bins_k), the rest of the last 64-row block is zero;
+      // algorithmic flops of LAM * Pinv: 2 * n * (columns up to the last active bound) per running problem
+      EvScope es(h, 5, 2.0 * h->np * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun);
+      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((nrun + 63) / 64) * 64, h->np, h->np, nullptr, 0,
              h->asm_counters + 3);
     }
     {
       EvScope es(h, 6, 0.0);
       hipLaunchKernelGGL(asm_update_k, dim3(nprob), dim3(256), 0, s, a);
     }
-    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    h->stats.asm_rounds += 1;
-    // algorithmic flops of this round's LAM * Pinv: 2 * n * (columns up to the last active bound) per running problem
-    h->stats.asm_gemm_flops += 2.0 * h->np * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun;
-    nrun = cnt[0];
-    if (cnt[0] == 0) break;
   }
   // certification with P itself: px = x P (only finished rows matter)
   gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);
@@ -1033,7 +1042,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NBIN * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_work, 2 * G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_qinf, G); A_(h->asm_work, 2 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
