@@ -50,7 +50,8 @@ static __global__ __launch_bounds__(256) void gemm_nt_f64_k(double* __restrict__
                                                      const double* __restrict__ A, size_t lda,
                                                      const double* __restrict__ B, size_t ldb,
                                                      int K, const int* __restrict__ rowphase,
-                                                     int want, const int* __restrict__ kdyn = nullptr) {
+                                                     int want, const int* __restrict__ kdyn = nullptr,
+                                                     const int* __restrict__ mdyn = nullptr) {
   constexpr int LD = 18;
   // kdyn (nullable): device-side bound on the non-zero columns of A (last non-zero column index);
   // the k-loop stops there -- LAM rows of the active-set pass are zero beyond the last active bound
@@ -60,6 +61,7 @@ static __global__ __launch_bounds__(256) void gemm_nt_f64_k(double* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  if (mdyn && m0 >= *mdyn) return;                          // device-side row count (rows beyond it are not needed)
   if (rowphase) {
     const int need = tid < 64 ? (rowphase[m0 + tid] == want) : 0;
     if (!__syncthreads_or(need)) return;

@@ -25,10 +25,11 @@ namespace nnmpc {
 
 constexpr int ASM_MLDS = 176;      // largest active set factored in LDS (11 x 11 lower 16x16 fp64 tiles)
 constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: conflict-free MFMA operand reads)
-enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3 };   // CERT: finished and certified by the inverse-error bound
+enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4 };   // CERT: finished and certified by the inverse-error bound
 constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
 constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds) run the register kernel, the others the LDS-tile kernel
 constexpr int ASM_NCNT = 16;       // ints in AsmDev::counters
+constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
 
 struct AsmDev {
@@ -61,6 +62,12 @@ struct AsmDev {
   int* row;                        // [nseg] row of lam / xh this round: the running problems are packed into rows
                                    // 0..nrun-1 (counters[2]), so the GEMM only covers those
   double* qinf;                    // [nseg] max |q| (for the certificate)
+  int W;                           // columns evaluated in this round (multiple of 64, past the last active bound of any
+                                   // running problem + a margin); W < n: a problem that settles inside the window is
+                                   // handed to the full-width check (asm_wide_k) through the lists below
+  double* lamw;                    // [rows] multiplier rows of the problems awaiting the full-width check
+  const double* xhw;               // [rows] = lamw * H, all columns
+  int* wlist;                      // [nseg] those problems; their number is counters[8]
   double* work;                    // [nseg][2] statistics: fp64 flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
@@ -147,7 +154,8 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // covers only those) and a place in the list of their size class -- exclusive scans over the
 // problems instead of one same-address atomic per problem, which cost more than the factorisations'
 // launch.  counters: [0] = [2] = nrun, [1] sets too large for LDS, [3] largest active variable index,
-// [4 + b] length of size-class list b.
+// [4 + b] length of size-class list b.  counters[ASM_CNT_WIDE] (filled by asm_update_k, consumed by asm_wide_k
+// earlier in the round) is reset here.
 __global__ __launch_bounds__(1024) void asm_bins_k(AsmDev d) {
   constexpr int NC = 2 + ASM_NBIN;                           // rows, big list, size classes
   __shared__ int wtot[NC][16];
@@ -208,6 +216,8 @@ __global__ __launch_bounds__(1024) void asm_bins_k(AsmDev d) {
     int k = 0;
     for (int w = 0; w < 16; ++w) k = max(k, kred[w]);
     d.counters[3] = k;
+    d.counters[ASM_CNT_WIDE + 1] = d.counters[ASM_CNT_WIDE];   // how many asm_wide_k just handled (statistics)
+    d.counters[ASM_CNT_WIDE] = 0;
   }
 }
 
@@ -665,13 +675,15 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
 __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
   __shared__ int cnt[4];
   __shared__ double red[12];
+  __shared__ int s_wrow;
   const int p = blockIdx.x, tid = threadIdx.x;
   if (d.state[p] != ASM_RUN) return;
   const size_t o = (size_t)p * d.np, orow = (size_t)d.row[p] * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
+  const int W = min(d.W, d.n);                               // every active bound lies inside the window
   int chg = 0;
   double l1 = 0.0, lmin = 1e300;
-  for (int r = tid; r < d.n; r += 256) {
+  for (int r = tid; r < W; r += 256) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     const int s = st[r];
@@ -681,7 +693,6 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
       else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
     } else {
       const double l = d.lam[orow + r];
-      d.lam[orow + r] = 0.0;                                 // the LAM rows stay zero outside the sets in flight
       l1 += fabs(l); lmin = fmin(lmin, fabs(l));
       if ((s == 1 && l <= 0.0) || (s == 2 && l >= 0.0)) { st[r] = 0; ++chg; }   // keep iff multiplier > 0
     }
@@ -699,7 +710,23 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
   }
   __syncthreads();
   const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-  if (tot == 0) {                                            // finished: only now x is written out
+  const bool settle_wide = tot == 0 && W < d.n;              // settled inside the window: full-width check next
+  if (settle_wide && tid == 0) {
+    const int w = atomicAdd(&d.counters[ASM_CNT_WIDE], 1);   // once per problem (and re-entry), not per round
+    d.wlist[w] = p;
+    s_wrow = w;
+  }
+  __syncthreads();
+  // the LAM row goes back to zero (rows are handed out anew every round); a settled problem takes its
+  // multipliers along into its row of LAMW
+  {
+    double* lw = settle_wide ? d.lamw + (size_t)s_wrow * d.np : nullptr;
+    for (int r = tid; r < W; r += 256) {
+      const double l = d.lam[orow + r];
+      if (l != 0.0) { d.lam[orow + r] = 0.0; if (lw) lw[r] = l; }
+    }
+  }
+  if (tot == 0 && !settle_wide) {                            // finished: only now x is written out
     for (int r = tid; r < d.n; r += 256) {
       const int k = r % d.nu, s = st[r];
       d.x[o + r] = s == 0 ? d.xunc[o + r] - d.xh[orow + r]
@@ -709,7 +736,8 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
   if (tid == 0) {
     const int rd = d.rounds[p] + 1;
     d.rounds[p] = rd;
-    if (tot == 0) {
+    if (settle_wide) d.state[p] = ASM_WIDE;
+    else if (tot == 0) {
       const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
       const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
       const double QI = d.qinf[p];
@@ -717,6 +745,61 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
       const bool sure = bnd <= d.stat_tol * fmax(d.pscale, QI) && LM > bnd;
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
     } else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
+  }
+}
+
+// Full-width check of the problems that settled inside the window (xhw = lamw * H over all columns):
+// a bound violated beyond the window joins the set and the problem runs on; otherwise it is finished
+// exactly like in asm_update_k.  Runs at the start of a round, before asm_count_k.
+__global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
+  __shared__ int cnt[4];
+  __shared__ double red[12];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  if (w >= d.counters[ASM_CNT_WIDE]) return;
+  const int p = d.wlist[w];
+  const size_t o = (size_t)p * d.np, orow = (size_t)w * d.np;
+  unsigned char* st = d.st + (size_t)p * d.n;
+  int chg = 0;
+  double l1 = 0.0, lmin = 1e300;
+  for (int r = tid; r < d.n; r += 256) {
+    const int k = r % d.nu;
+    const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
+    const int s = st[r];
+    double x;
+    if (s == 0) {
+      x = d.xunc[o + r] - d.xhw[orow + r];
+      if (x > ub + d.bound_tol) { st[r] = 1; ++chg; }
+      else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
+    } else {
+      const double l = d.lamw[orow + r];
+      d.lamw[orow + r] = 0.0;
+      l1 += fabs(l); lmin = fmin(lmin, fabs(l));
+      x = s == 1 ? ub : lb;
+    }
+    d.x[o + r] = x;                                          // final if nothing changes
+  }
+  double x1 = 0.0;
+  for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
+  for (int off = 32; off > 0; off >>= 1) {
+    chg += __shfl_xor(chg, off);
+    l1 += __shfl_xor(l1, off); x1 += __shfl_xor(x1, off);
+    lmin = fmin(lmin, __shfl_xor(lmin, off));
+  }
+  if ((tid & 63) == 0) {
+    const int wv = tid >> 6;
+    cnt[wv] = chg; red[wv] = l1; red[4 + wv] = x1; red[8 + wv] = lmin;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (tot == 0) {
+      const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
+      const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
+      const double QI = d.qinf[p];
+      const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
+      const bool sure = bnd <= d.stat_tol * fmax(d.pscale, QI) && LM > bnd;
+      d.state[p] = sure ? ASM_CERT : ASM_DONE;
+    } else d.state[p] = d.rounds[p] >= d.max_rounds ? ASM_FALLBACK : ASM_RUN;
   }
 }
 

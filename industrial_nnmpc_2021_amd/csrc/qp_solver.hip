@@ -612,7 +612,8 @@ struct nnmpc_qp {
   bool have_inverse;
   double* H64;      // np x np
   double* Kunc64;   // np x ka
-  double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch;
+  double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch, *asm_lamw, *asm_xhw;
+  int* asm_wlist;
   unsigned char* asm_st;
   int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row;
   double* asm_qinf;
@@ -703,9 +704,9 @@ void gemm32(nnmpc_qp* h, float* C, size_t ldc, const float* A, size_t lda, const
 }
 void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, const double* B,
             size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0,
-            const int* kdyn = nullptr) {
+            const int* kdyn = nullptr, const int* mdyn = nullptr) {
   dim3 grid(N / 64, M / 64);
-  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want, kdyn);
+  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want, kdyn, mdyn);
 }
 
 template <int NB>
@@ -841,7 +842,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.qinf = h->asm_qinf; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.qinf = h->asm_qinf; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   HIPCHK(hipMemsetAsync(h->asm_lam, 0, (size_t)segp * h->np * sizeof(double), s));
@@ -849,7 +850,20 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   const int lds_big = (a.max_active + ASM_TS) * 8;
   int cnt[ASM_NCNT] = {0};
   int rounds = 0;
-  for (; rounds < a.max_rounds + 1; ++rounds) {
+  int prev_run = 0;                                     // upper bound of the problems awaiting the full-width check
+  int kprev = 0;
+  HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
+  for (; rounds < 2 * a.max_rounds + 2; ++rounds) {
+    if (prev_run) {
+      // problems that settled inside last round's column window: all columns of x, once
+      {
+        EvScope es(h, 5, 0.0);
+        gemm64(h, h->asm_xhw, h->np, h->asm_lamw, h->np, h->H64, h->np, ((prev_run + 63) / 64) * 64, h->np, h->np, nullptr, 0,
+               h->asm_counters + 3, h->asm_counters + ASM_CNT_WIDE);
+      }
+      EvScope es(h, 6, 0.0);
+      hipLaunchKernelGGL(asm_wide_k, dim3(prev_run), dim3(256), 0, s, a);
+    }
     {
       EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
       hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
@@ -858,8 +872,14 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int nrun = cnt[0];
+    if (h->profiling)                                   // flops of the full-width pass that opened this round
+      h->stats.asm_gemm_flops += 2.0 * h->np * (double)std::min(h->np, ((kprev + 16) / 16) * 16) * cnt[ASM_CNT_WIDE + 1];
+    kprev = cnt[3];
     if (nrun == 0) break;
     h->stats.asm_rounds += 1;
+    // column window of this round: past the last active bound of any running problem plus four stages; a
+    // problem that settles inside it gets one full-width pass (asm_wide_k) at the start of the next round
+    a.W = std::min(h->np, ((cnt[3] + 1 + 4 * h->nu + 63) / 64) * 64);
     {
       EvScope es(h, 4, 0.0);
       // size classes 0..ASM_NREG-1 (<= 144 bounds): one wave per problem, S in registers, one launch.  The
@@ -886,14 +906,15 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     {
       // the running problems sit in rows 0..nrun-1 of LAM (asm_bins_k), the rest of the last 64-row block is zero;
       // algorithmic flops of LAM * Pinv: 2 * n * (columns up to the last active bound) per running problem
-      EvScope es(h, 5, 2.0 * h->np * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun);
-      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((nrun + 63) / 64) * 64, h->np, h->np, nullptr, 0,
+      EvScope es(h, 5, 2.0 * a.W * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun);
+      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((nrun + 63) / 64) * 64, a.W, h->np, nullptr, 0,
              h->asm_counters + 3);
     }
     {
       EvScope es(h, 6, 0.0);
       hipLaunchKernelGGL(asm_update_k, dim3(nprob), dim3(256), 0, s, a);
     }
+    prev_run = a.W < h->n ? nrun : 0;
   }
   // certification with P itself: px = x P (only finished rows matter)
   gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);
@@ -1040,6 +1061,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->asm_pool = 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
+  A_(h->asm_lamw, G * np); A_(h->asm_xhw, G * np); A_(h->asm_wlist, G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NBIN * G);
   A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_qinf, G); A_(h->asm_work, 2 * G);
