@@ -1,0 +1,104 @@
+"""GPU parity tests of the active-set fast path (qp_asm.h) on generic box QPs, through the C ABI.
+
+Every size class of the multiplier-system kernels (register-resident 4..9 blocks, LDS tiles 10..11
+blocks, the L2-slab kernel beyond) and the column-window / full-width re-entry logic get their own
+cases; the oracle is the fp64 interior-point + active-set restatement in oracle/qp.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import qp as oqp
+
+pytestmark = pytest.mark.gpu
+
+
+def _spd(n, seed, cond=50.0):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.exp(rng.uniform(0.0, np.log(cond), n))
+    return (Q * ev) @ Q.T
+
+
+def _solve_ref(P, q, lb, ub, nu):
+    n = q.size
+    info = {"nu": nu}
+    x = oqp.solve_exact_box(P, q, np.tile(lb, n // nu), np.tile(ub, n // nu), info=info)
+    act = np.zeros(2 * n, bool)
+    act[info["active"]] = True
+    return x, act
+
+
+def _qp(P, nu, **kw):
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    n = P.shape[0]
+    return BatchedBoxQP(P, np.eye(n), nu, method="asm", max_batch=128, **kw)   # tq = I: q = x0
+
+
+@pytest.mark.parametrize("n_active_target", [20, 60, 72, 85, 98, 110, 122, 135, 145, 230])
+def test_size_classes(n_active_target):
+    """Sets of ~20 .. ~280 bounds (the couplings add ~20 % to the pushed ones): every kernel variant must
+    reproduce the exact optimum and set."""
+    n, nu, B = 512, 8, 12
+    P = _spd(n, 7)
+    rng = np.random.default_rng(n_active_target)
+    lb, ub = -np.ones(nu), np.ones(nu)
+    # the first n_active_target variables are pushed far beyond a bound, the others stay interior
+    q = 0.05 * rng.standard_normal((B, n))
+    push = rng.choice([-1.0, 1.0], (B, n_active_target)) * rng.uniform(30.0, 60.0, (B, n_active_target))
+    q[:, :n_active_target] += push * np.diag(P)[:n_active_target]
+    qp = _qp(P, nu)
+    out = qp.solve_batch(q, lb, ub)
+    st = qp.stats()
+    assert (out["status"] == 0).all(), out["status"]
+    assert st["asm_solved"] == B and st["factorizations"] == 0     # no silent PDIP fallback
+    sizes = []
+    for b in range(B):
+        x, act = _solve_ref(P, q[b], lb, ub, nu)
+        err = np.abs(out["u"][b] - x).max() / max(1.0, np.abs(x).max())
+        assert err <= 1e-9, (b, err)
+        assert (out["active"][b] == act).all(), (b, np.argwhere(out["active"][b] != act)[:8])
+        sizes.append(int(act.sum()))
+    assert min(sizes) >= 0.6 * n_active_target and max(sizes) <= 1.4 * n_active_target + 16, sizes
+
+
+def test_window_reentry_far_violation():
+    """A bound far beyond the column window is violated only once an early bound is clamped: the
+    full-width pass must find it and send the problem back into the rounds."""
+    n, nu = 2048, 8
+    P = np.eye(n)
+    f = n - 3
+    P[0, f] = P[f, 0] = -0.8
+    lb, ub = -np.ones(nu), np.ones(nu)
+    B = 6
+    rng = np.random.default_rng(3)
+    q = 0.01 * rng.standard_normal((B, n))
+    q[:, 0] += -4.28                       # x_unc[0] ~ 5 (> ub), x_unc[f] ~ 0.9; with x[0] = 1: x[f] = -2.3 (< lb)
+    q[:, f] += 3.1
+    q[B - 1] = 0.01 * rng.standard_normal(n)      # one sample with nothing active at all
+    qp = _qp(P, nu)
+    out = qp.solve_batch(q, lb, ub)
+    st = qp.stats()
+    assert (out["status"] == 0).all() and st["asm_solved"] == B
+    for b in range(B):
+        x, act = _solve_ref(P, q[b], lb, ub, nu)
+        assert np.abs(out["u"][b] - x).max() <= 1e-10
+        assert (out["active"][b] == act).all()
+    assert abs(out["u"][0, 0] - 1.0) < 1e-12 and abs(out["u"][0, f] + 1.0) < 1e-12
+    assert not out["active"][B - 1].any()
+
+
+def test_window_wide_sets_match_full_width():
+    """Active bounds in late stages make the window as wide as the problem: same answers as the oracle."""
+    n, nu, B = 768, 4, 8
+    P = _spd(n, 11, cond=200.0)
+    rng = np.random.default_rng(5)
+    lb, ub = -0.5 * np.ones(nu), 0.8 * np.ones(nu)
+    q = 0.3 * rng.standard_normal((B, n)) * np.sqrt(np.diag(P))
+    q[:, -5:] += 40.0 * np.diag(P)[-5:]
+    qp = _qp(P, nu)
+    out = qp.solve_batch(q, lb, ub)
+    assert (out["status"] == 0).all() and qp.stats()["asm_solved"] == B
+    for b in range(B):
+        x, act = _solve_ref(P, q[b], lb, ub, nu)
+        assert np.abs(out["u"][b] - x).max() / max(1.0, np.abs(x).max()) <= 1e-9
+        assert (out["active"][b] == act).all()
