@@ -1045,8 +1045,12 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.nfac, S); A_(d.prounds, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.stale, S); A_(d.rz, S);
   A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
   {
-    // segment size: as many problems as ~1.5 GB of (q f64 + warm start f32) rows allow
-    long long cap = (long long)(3.0e9 / (12.0 * np + 32.0 * np + n));
+    // segment size: as many problems as a quarter of the free HBM allows (per problem: q f64, warm start f32 and the
+    // six f64 rows of the active-set pass, its set list and bound states).  Large segments amortise the thinly
+    // populated last rounds of the active-set pass.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)12e9;
+    long long cap = (long long)(0.25 * (double)free_b / (12.0 * np + 48.0 * np + n + 4.0 * o.asm_max_active + 64.0));
     cap = std::max<long long>(cap, S);
     cap = std::min<long long>(cap, 1 << 20);
     h->seg_max = (int)((cap / 128) * 128);
