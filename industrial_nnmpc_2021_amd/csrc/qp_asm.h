@@ -29,7 +29,9 @@ enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4 }
 constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
 constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds) run the register kernel, the others the LDS-tile kernel
 constexpr int ASM_NCNT = 16;       // ints in AsmDev::counters
-constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check
+constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check ([13]: handled by the last asm_wide_k)
+constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
+constexpr int ASM_NSCAN = ASM_NBIN + 3;   // scan columns: running, large sets, size classes, max active index
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
 
 struct AsmDev {
@@ -61,7 +63,9 @@ struct AsmDev {
   int* mg;                         // [nseg] their number
   int* row;                        // [nseg] row of lam / xh this round: the running problems are packed into rows
                                    // 0..nrun-1 (counters[2]), so the GEMM only covers those
-  double* qinf;                    // [nseg] max |q| (for the certificate)
+  double tqmax;                    // max |tq| entry: |q|_inf <= tqmax |x0|_1 (q itself is only formed for the full check)
+  int* lrank;                      // [nseg] asm_bins scratch: rank inside its chunk and list
+  int* ctot;                       // [chunks][ASM_NSCAN] asm_bins scratch: per-chunk totals, last column: max active index
   int W;                           // columns evaluated in this round (multiple of 64, past the last active bound of any
                                    // running problem + a margin); W < n: a problem that settles inside the window is
                                    // handed to the full-width check (asm_wide_k) through the lists below
@@ -82,39 +86,22 @@ __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1)
 
 // x_unc -> first active-set estimate: every bound the unconstrained minimiser violates.
 __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
-  __shared__ int cnt[4];
-  __shared__ double qm[4];
   const int p = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)p * d.np;
   if (p >= d.nseg) {                 // padding rows of the GEMM operands: never active
     if (tid == 0) d.state[p] = ASM_DONE;
     return;
   }
-  int c = 0;
-  double qi = 0.0;
   for (int r = tid; r < d.n; r += 256) {
     const int k = r % d.nu;
     const double x = d.xunc[o + r];
-    qi = fmax(qi, fabs(d.q64[o + r]));
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     int s = x > ub ? 1 : (x < lb ? 2 : 0);
     if (d.guess) { s = d.guess[(size_t)p * d.n + r]; if (s > 2) s = 0; }
     d.st[(size_t)p * d.n + r] = (unsigned char)s;
-    d.x[o + r] = s == 1 ? ub : (s == 2 ? lb : x);
-    c += s != 0;
   }
-  for (int r = d.n + tid; r < d.np; r += 256) d.x[o + r] = 0.0;
-  for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off); qi = fmax(qi, __shfl_xor(qi, off)); }
-  if ((tid & 63) == 0) { cnt[tid >> 6] = c; qm[tid >> 6] = qi; }
-  __syncthreads();
-  if (tid == 0) {
-    const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    d.rounds[p] = 0;
-    d.qinf[p] = fmax(fmax(qm[0], qm[1]), fmax(qm[2], qm[3]));
-    // empty set: x = x_unc; done if that is feasible, which the first update round decides when the
-    // set came from a caller's guess
-    d.state[p] = (tot == 0 && !d.guess) ? ASM_DONE : ASM_RUN;
-  }
+  // an empty set runs one round like the others: x = x_unc is checked and certified by asm_update_k / asm_wide_k
+  if (tid == 0) { d.rounds[p] = 0; d.state[p] = ASM_RUN; }
 }
 
 // Round stage 0a: ordered list of the active indices of every running problem and its length.
@@ -150,75 +137,85 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   }
 }
 
-// Round stage 0b (one workgroup): the running problems get the rows 0..nrun-1 of LAM / XH (the GEMM
-// covers only those) and a place in the list of their size class -- exclusive scans over the
-// problems instead of one same-address atomic per problem, which cost more than the factorisations'
-// launch.  counters: [0] = [2] = nrun, [1] sets too large for LDS, [3] largest active variable index,
-// [4 + b] length of size-class list b.  counters[ASM_CNT_WIDE] (filled by asm_update_k, consumed by asm_wide_k
-// earlier in the round) is reset here.
-__global__ __launch_bounds__(1024) void asm_bins_k(AsmDev d) {
-  constexpr int NC = 2 + ASM_NBIN;                           // rows, big list, size classes
-  __shared__ int wtot[NC][16];
-  __shared__ int kred[16];
+// Round stage 0b: the running problems get the rows 0..nrun-1 of LAM / XH (the GEMM covers only those)
+// and a place in the list of their size class -- by exclusive scans over the problems (chunks of 1024 per
+// workgroup: ranks inside the chunk from wave ballots, then the chunk totals) instead of one same-address
+// atomic per problem, which cost more than the factorisations' launch.
+// counters: [0] = [2] = nrun, [1] sets too large for LDS, [3] largest active variable index, [4 + b] length
+// of size-class list b.  counters[ASM_CNT_WIDE] (filled by asm_update_k, consumed by asm_wide_k earlier in
+// the round) is reset here.
+__device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + b size class b
+  run = p < d.nseg && d.state[p] == ASM_RUN;
+  if (!run) return -1;
+  const int m = d.mg[p];
+  return m > ASM_MLDS ? 0 : 1 + max((m + 15) / 16, 4) - 4;
+}
+__global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
+  __shared__ int wtot[ASM_NSCAN][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (d.nseg + 1023) / 1024;
-  const int p0 = min(d.nseg, tid * per), p1 = min(d.nseg, p0 + per);
-  int c[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) c[i] = 0;
-  int kmax = 0;
-  for (int p = p0; p < p1; ++p) {
-    if (d.state[p] != ASM_RUN) continue;
-    const int m = d.mg[p];
-    c[0] += 1;
-    if (m > ASM_MLDS) c[1] += 1;
-    else {
-      const int b = max((m + 15) / 16, 4) - 4;
-#pragma unroll
-      for (int i = 0; i < ASM_NBIN; ++i) c[2 + i] += (i == b);
-    }
-    if (m > 0) kmax = max(kmax, d.idxg[(size_t)p * d.max_active + m - 1]);
+  const int p = blockIdx.x * 1024 + tid;
+  bool run;
+  const int col = asm_scan_col(d, p, run);
+  int kl = 0;
+  if (run) { const int m = d.mg[p]; if (m > 0) kl = d.idxg[(size_t)p * d.max_active + m - 1]; }
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int myrank = 0, myrow = 0;
+  {
+    const unsigned long long mk = __ballot(run);
+    myrow = __popcll(mk & lt);
+    if (lane == 0) wtot[0][wave] = __popcll(mk);
   }
-  int base[NC];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    int inc = c[i];
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-    if (lane == 63) wtot[i][wave] = inc;
-    base[i] = inc - c[i];
+  for (int c = 0; c <= ASM_NBIN; ++c) {
+    const unsigned long long mk = __ballot(col == c);
+    if (col == c) myrank = __popcll(mk & lt);
+    if (lane == 0) wtot[1 + c][wave] = __popcll(mk);
   }
-  for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
-  if (lane == 0) kred[wave] = kmax;
+  for (int off = 32; off > 0; off >>= 1) kl = max(kl, __shfl_xor(kl, off));
+  if (lane == 0) wtot[ASM_NSCAN - 1][wave] = kl;
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NC; ++i)
-    for (int w = 0; w < wave; ++w) base[i] += wtot[i][w];
-  for (int p = p0; p < p1; ++p) {
-    if (d.state[p] != ASM_RUN) continue;
-    const int m = d.mg[p];
-    d.row[p] = base[0]++;
-    if (m > ASM_MLDS) d.biglist[base[1]++] = p;
-    else {
-      const int b = max((m + 15) / 16, 4) - 4;
-#pragma unroll
-      for (int i = 0; i < ASM_NBIN; ++i)
-        if (i == b) d.binlist[(size_t)i * d.nseg + base[2 + i]++] = p;
+  if (run) {
+    for (int w = 0; w < wave; ++w) { myrow += wtot[0][w]; myrank += wtot[1 + col][w]; }
+    d.row[p] = myrow;
+    d.lrank[p] = myrank;
+  }
+  if (tid < ASM_NSCAN) {
+    int t = 0;
+    if (tid == ASM_NSCAN - 1) { for (int w = 0; w < 16; ++w) t = max(t, wtot[tid][w]); }
+    else { for (int w = 0; w < 16; ++w) t += wtot[tid][w]; }
+    d.ctot[(size_t)blockIdx.x * ASM_NSCAN + tid] = t;
+  }
+}
+__global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
+  __shared__ int base[ASM_NSCAN];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x * 1024 + tid;
+  if (tid < ASM_NSCAN) {
+    int t = 0;
+    if (tid == ASM_NSCAN - 1) { for (int j = 0; j < (int)gridDim.x; ++j) t = max(t, d.ctot[(size_t)j * ASM_NSCAN + tid]); }
+    else { for (int j = 0; j < (int)blockIdx.x; ++j) t += d.ctot[(size_t)j * ASM_NSCAN + tid]; }
+    base[tid] = t;
+    if (blockIdx.x == gridDim.x - 1) {                       // the last chunk knows the totals
+      if (tid == ASM_NSCAN - 1) {
+        d.counters[3] = t;
+        d.counters[ASM_CNT_WIDE + 1] = d.counters[ASM_CNT_WIDE];   // how many asm_wide_k just handled (statistics)
+        d.counters[ASM_CNT_WIDE] = 0;
+      } else {
+        const int tot = t + d.ctot[(size_t)blockIdx.x * ASM_NSCAN + tid];
+        if (tid == 0) { d.counters[0] = tot; d.counters[2] = tot; }
+        else if (tid == 1) d.counters[1] = tot;
+        else d.counters[4 + tid - 2] = tot;
+      }
     }
   }
-  if (tid < NC) {
-    int t = 0;
-    for (int w = 0; w < 16; ++w) t += wtot[tid][w];
-    if (tid == 0) { d.counters[0] = t; d.counters[2] = t; }
-    else if (tid == 1) d.counters[1] = t;
-    else d.counters[4 + tid - 2] = t;
-  }
-  if (tid == 32) {
-    int k = 0;
-    for (int w = 0; w < 16; ++w) k = max(k, kred[w]);
-    d.counters[3] = k;
-    d.counters[ASM_CNT_WIDE + 1] = d.counters[ASM_CNT_WIDE];   // how many asm_wide_k just handled (statistics)
-    d.counters[ASM_CNT_WIDE] = 0;
-  }
+  __syncthreads();
+  bool run;
+  const int col = asm_scan_col(d, p, run);
+  if (!run) return;
+  d.row[p] += base[0];
+  const int pos = base[1 + col] + d.lrank[p];
+  if (col == 0) d.biglist[pos] = p;
+  else d.binlist[(size_t)(col - 1) * d.nseg + pos] = p;
 }
 
 // One problem: r_A = x_unc,A - b_A, S = H_AA as 16 x 16 fp64 tiles, blocked right-looking
@@ -740,10 +737,11 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
     else if (tot == 0) {
       const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
       const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
-      const double QI = d.qinf[p];
+      const double QI = d.tqmax * X1;                        // >= |q|_inf
       const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
-      const bool sure = bnd <= d.stat_tol * fmax(d.pscale, QI) && LM > bnd;
+      const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
+      if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);    // rare: q and x P are formed only for these
     } else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
   }
 }
@@ -795,10 +793,11 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
     if (tot == 0) {
       const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
       const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
-      const double QI = d.qinf[p];
+      const double QI = d.tqmax * X1;                        // >= |q|_inf
       const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
-      const bool sure = bnd <= d.stat_tol * fmax(d.pscale, QI) && LM > bnd;
+      const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
+      if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);    // rare: q and x P are formed only for these
     } else d.state[p] = d.rounds[p] >= d.max_rounds ? ASM_FALLBACK : ASM_RUN;
   }
 }

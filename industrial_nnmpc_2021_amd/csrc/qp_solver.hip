@@ -615,8 +615,8 @@ struct nnmpc_qp {
   double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch, *asm_lamw, *asm_xhw;
   int* asm_wlist;
   unsigned char* asm_st;
-  int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row;
-  double* asm_qinf;
+  int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row, *asm_lrank, *asm_ctot;
+  double tqmax;         // max |tq| entry
   int asm_pool;
   double asm_e1max, asm_e2max;
   double* asm_work;
@@ -832,7 +832,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   hipStream_t s = h->stream;
   const int segp = ((nprob + 127) / 128) * 128;
   hipLaunchKernelGGL(pad_x0_k, dim3(512), dim3(256), 0, s, h->x0_64, h->x0_32, x0_dev, nprob, h->n_aug, h->ka, segp);
-  gemm64(h, h->q64_all, h->np, h->x0_64, h->ka, h->tq64, h->ka, segp, h->np, h->ka);
+  // x_unc = Kunc x0 for the whole segment; q = tq x0 is only formed for the rows that need the full check with P
   gemm64(h, h->asm_xunc, h->np, h->x0_64, h->ka, h->Kunc64, h->ka, segp, h->np, h->ka);
   AsmDev a;
   a.n = h->n; a.np = h->np; a.nu = h->nu; a.nseg = nprob;
@@ -842,10 +842,11 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.qinf = h->asm_qinf; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
-  HIPCHK(hipMemsetAsync(h->asm_lam, 0, (size_t)segp * h->np * sizeof(double), s));
+  // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
+  // asm_update_k / asm_wide_k of the same round
   hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
   const int lds_big = (a.max_active + ASM_TS) * 8;
   int cnt[ASM_NCNT] = {0};
@@ -867,7 +868,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     {
       EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
       hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
-      hipLaunchKernelGGL(asm_bins_k, dim3(1), dim3(1024), 0, s, a);
+      hipLaunchKernelGGL(asm_bins_a_k, dim3((nprob + 1023) / 1024), dim3(1024), 0, s, a);
+      hipLaunchKernelGGL(asm_bins_b_k, dim3((nprob + 1023) / 1024), dim3(1024), 0, s, a);
     }
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -916,8 +918,11 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
     prev_run = a.W < h->n ? nrun : 0;
   }
-  // certification with P itself: px = x P (only finished rows matter)
-  gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);
+  // certification with P itself (rows the inverse-error bound could not certify): q = tq x0 and px = x P
+  if (cnt[ASM_CNT_DONE] > 0) {
+    gemm64(h, h->q64_all, h->np, h->x0_64, h->ka, h->tq64, h->ka, segp, h->np, h->ka, h->asm_state, ASM_DONE);
+    gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);
+  }
   hipLaunchKernelGGL(asm_certify_k, dim3(nprob), dim3(256), 0, s, a, h->pscale);
   std::vector<int> st(nprob);
   HIPCHK(hipMemcpyAsync(st.data(), h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1068,7 +1073,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_lamw, G * np); A_(h->asm_xhw, G * np); A_(h->asm_wlist, G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NBIN * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_qinf, G); A_(h->asm_work, 2 * G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_work, 2 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
@@ -1113,9 +1118,11 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
           t[(size_t)r * NB + c] = v;
         }
     }
+  h->tqmax = 0.0;
   for (int r = 0; r < n; ++r)
     for (int k = 0; k < n_aug; ++k) {
       t64[(size_t)r * ka + k] = tq[(size_t)r * n_aug + k];
+      h->tqmax = std::max(h->tqmax, std::fabs(tq[(size_t)r * n_aug + k]));
       if (Kunc) k32[(size_t)r * ka + k] = (float)Kunc[(size_t)r * n_aug + k];
     }
   hipError_t e = hipSuccess;
