@@ -90,13 +90,14 @@ typedef struct {
   int64_t asm_rounds;        /* lock-step rounds of the active-set pass */
   int64_t asm_gemm_launches; /* launches of its dominant kernel (gemm_nt_f64_k: LAM * Hinv) */
   double asm_gemm_ms;        /* hipEvent time of those (profiling on) */
-  double asm_gemm_flops;     /* algorithmic flops: 2 n^2 per running problem and round */
-  double asm_lambda_ms;      /* hipEvent time of asm_lambda_k */
-  double asm_update_ms;      /* hipEvent time of asm_update_k */
+  double asm_gemm_flops;     /* algorithmic flops: 2 * columns evaluated * k_max per problem and round (+ one full-width pass) */
+  double asm_lambda_ms;      /* hipEvent time of the multiplier-system kernels (asm_lambda_reg_k, asm_lambda_tile_k) */
+  double asm_update_ms;      /* hipEvent time of the set bookkeeping (asm_count_k, asm_bins_*_k, asm_update_k, asm_wide_k) */
   double asm_lambda_flops;   /* algorithmic fp64 flops of the multiplier systems: sum of m^3/3 + 2 m^2 */
   double asm_lambda_bytes;   /* ... and their algorithmic bytes (gathered Pinv block + rhs/result) */
   double asm_e1max;          /* max |P Kunc + tq| of the verified inverse (nnmpc_qp_set_inverse) */
   double asm_e2max;          /* max |P Pinv - I| */
+  int64_t asm_full_checks;   /* finished problems the inverse-error bound could not certify: checked with P itself */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);

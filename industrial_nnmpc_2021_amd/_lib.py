@@ -26,7 +26,7 @@ class QpStats(C.Structure):
                 ("asm_rounds", C.c_int64), ("asm_gemm_launches", C.c_int64), ("asm_gemm_ms", C.c_double),
                 ("asm_gemm_flops", C.c_double), ("asm_lambda_ms", C.c_double), ("asm_update_ms", C.c_double), ("asm_lambda_flops", C.c_double),
                 ("asm_lambda_bytes", C.c_double), ("asm_e1max", C.c_double),
-                ("asm_e2max", C.c_double)]
+                ("asm_e2max", C.c_double), ("asm_full_checks", C.c_int64)]
 
 
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",

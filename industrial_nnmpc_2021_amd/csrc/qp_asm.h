@@ -110,10 +110,20 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (d.state[p] != ASM_RUN) return;
   const unsigned char* st = d.st + (size_t)p * d.n;
-  const int per = (d.n + 255) / 256;
-  const int r0 = tid * per, r1 = min(d.n, r0 + per);
+  const bool words = (d.n & 3) == 0;                         // rows of st are then 4-byte aligned: 4 bounds per load
+  const int nw = words ? d.n >> 2 : d.n;                     // items (dwords or bytes), a contiguous run per thread
+  const int per = (nw + 255) / 256;
+  const int j0 = min(nw, tid * per), j1 = min(nw, j0 + per);
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(st);
   int c = 0;
-  for (int r = r0; r < r1; ++r) c += st[r] != 0;
+  if (words) {
+    for (int j = j0; j < j1; ++j) {
+      const uint32_t w = sw[j];
+      c += ((w & 0xffu) != 0) + ((w & 0xff00u) != 0) + ((w & 0xff0000u) != 0) + ((w & 0xff000000u) != 0);
+    }
+  } else {
+    for (int j = j0; j < j1; ++j) c += st[j] != 0;
+  }
   int inc = c;
   for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
   if (lane == 63) wsum[wave] = inc;
@@ -121,10 +131,20 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   int base = inc - c;
   for (int w = 0; w < wave; ++w) base += wsum[w];
   const int m = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  if (m <= d.max_active) {
+  if (m <= d.max_active && c > 0) {
     int* idx = d.idxg + (size_t)p * d.max_active;
     int k = base;
-    for (int r = r0; r < r1; ++r) if (st[r]) idx[k++] = r;
+    if (words) {
+      for (int j = j0; j < j1; ++j) {
+        const uint32_t w = sw[j];
+        if (w & 0xffu) idx[k++] = 4 * j;
+        if (w & 0xff00u) idx[k++] = 4 * j + 1;
+        if (w & 0xff0000u) idx[k++] = 4 * j + 2;
+        if (w & 0xff000000u) idx[k++] = 4 * j + 3;
+      }
+    } else {
+      for (int j = j0; j < j1; ++j) if (st[j]) idx[k++] = j;
+    }
   }
   if (tid == 0) {
     d.mg[p] = m;
@@ -723,11 +743,18 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
       if (l != 0.0) { d.lam[orow + r] = 0.0; if (lw) lw[r] = l; }
     }
   }
-  if (tot == 0 && !settle_wide) {                            // finished: only now x is written out
-    for (int r = tid; r < d.n; r += 256) {
+  const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
+  const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
+  const double QI = d.tqmax * X1;                            // >= |q|_inf
+  const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
+  const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
+  if (tot == 0 && !settle_wide) {                            // finished: only now x is written out, straight into the
+    for (int r = tid; r < d.n; r += 256) {                   // caller's buffer (and as a GEMM row if P must confirm it)
       const int k = r % d.nu, s = st[r];
-      d.x[o + r] = s == 0 ? d.xunc[o + r] - d.xh[orow + r]
-                          : (s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+      const double x = s == 0 ? d.xunc[o + r] - d.xh[orow + r]
+                              : (s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+      d.u_out[(size_t)p * d.n + r] = x;
+      if (!sure) d.x[o + r] = x;
     }
   }
   if (tid == 0) {
@@ -735,11 +762,6 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
     d.rounds[p] = rd;
     if (settle_wide) d.state[p] = ASM_WIDE;
     else if (tot == 0) {
-      const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
-      const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
-      const double QI = d.tqmax * X1;                        // >= |q|_inf
-      const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
-      const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
       if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);    // rare: q and x P are formed only for these
     } else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
@@ -774,7 +796,7 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
       l1 += fabs(l); lmin = fmin(lmin, fabs(l));
       x = s == 1 ? ub : lb;
     }
-    d.x[o + r] = x;                                          // final if nothing changes
+    d.u_out[(size_t)p * d.n + r] = x;                        // final if nothing changes
   }
   double x1 = 0.0;
   for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
@@ -788,14 +810,17 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
     cnt[wv] = chg; red[wv] = l1; red[4 + wv] = x1; red[8 + wv] = lmin;
   }
   __syncthreads();
+  const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
+  const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
+  const double QI = d.tqmax * X1;                            // >= |q|_inf
+  const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
+  const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
+  if (tot == 0 && !sure) {                                   // P itself has to confirm this one: x as a GEMM row
+    for (int r = tid; r < d.n; r += 256) d.x[o + r] = d.u_out[(size_t)p * d.n + r];
+  }
   if (tid == 0) {
-    const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     if (tot == 0) {
-      const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
-      const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
-      const double QI = d.tqmax * X1;                        // >= |q|_inf
-      const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
-      const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
       if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);    // rare: q and x P are formed only for these
     } else d.state[p] = d.rounds[p] >= d.max_rounds ? ASM_FALLBACK : ASM_RUN;
@@ -803,7 +828,8 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
 }
 
 // Independent fp64 certification with P itself (px = x P):  stationarity on the free set,
-// multiplier signs on the active set, feasibility; writes the outputs of finished problems.
+// multiplier signs on the active set, feasibility; active-set bits and status of finished problems
+// (u itself was written by asm_update_k / asm_wide_k).
 __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min) {
   __shared__ int cnt[4];
   __shared__ double gq[4];
@@ -817,19 +843,18 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
   const unsigned char* st = d.st + (size_t)p * d.n;
   int bad = 0;
   double qm = 0.0, gf = 0.0;
-  for (int r = tid; r < d.n; r += 256) {
-    const int k = r % d.nu;
-    const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
-    const double x = d.x[o + r];
-    const int s = st[r];
-    if (stt == ASM_DONE) {                      // full check with P itself
+  if (stt == ASM_DONE) {                        // full check with P itself
+    for (int r = tid; r < d.n; r += 256) {
+      const int k = r % d.nu;
+      const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
+      const double x = d.x[o + r];
+      const int s = st[r];
       const double g = d.px[o + r] + d.q64[o + r];
       qm = fmax(qm, fabs(d.q64[o + r]));
       if (s == 0) { gf = fmax(gf, fabs(g)); bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); }
       else if (s == 1) bad += g >= 0.0;
       else bad += g <= 0.0;
     }
-    d.u_out[(size_t)p * d.n + r] = x;
   }
   for (int off = 32; off > 0; off >>= 1) {
     bad += __shfl_xor(bad, off);

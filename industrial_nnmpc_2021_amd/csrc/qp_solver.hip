@@ -919,6 +919,11 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     prev_run = a.W < h->n ? nrun : 0;
   }
   // certification with P itself (rows the inverse-error bound could not certify): q = tq x0 and px = x P
+  if (rounds >= 2 * a.max_rounds + 2) {                  // left by the round cap: the last counters are not final
+    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  h->stats.asm_full_checks += cnt[ASM_CNT_DONE];
   if (cnt[ASM_CNT_DONE] > 0) {
     gemm64(h, h->q64_all, h->np, h->x0_64, h->ka, h->tq64, h->ka, segp, h->np, h->ka, h->asm_state, ASM_DONE);
     gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);

@@ -102,3 +102,36 @@ def test_window_wide_sets_match_full_width():
         x, act = _solve_ref(P, q[b], lb, ub, nu)
         assert np.abs(out["u"][b] - x).max() / max(1.0, np.abs(x).max()) <= 1e-9
         assert (out["active"][b] == act).all()
+
+
+def test_full_check_with_P_when_inverse_is_only_approximate():
+    """An inverse good to ~1e-10 cannot certify by the error bound; the rows go through the independent
+    check with P itself (q = tq x0, x P) and must still come out solved, without the PDIP path."""
+    import ctypes as C
+    import scipy.linalg as sla
+    from industrial_nnmpc_2021_amd import _lib
+    n, nu, B = 512, 8, 16
+    P = _spd(n, 21, cond=20.0)
+    rng = np.random.default_rng(9)
+    lb, ub = -np.ones(nu), np.ones(nu)
+    q = 1.5 * rng.standard_normal((B, n)) * np.sqrt(np.diag(P))
+    qp = _qp(P, nu)
+    H = sla.cho_solve(sla.cho_factor(P), np.eye(n))
+    H = H * (1.0 + 2e-10 * rng.standard_normal((n, n)))
+    H = np.ascontiguousarray(0.5 * (H + H.T))
+    K = np.ascontiguousarray(-H)                       # tq = I  =>  Kunc = -Pinv
+    _lib.check(qp._lib.nnmpc_qp_set_inverse(qp._h, H.ctypes.data_as(C.c_void_p), K.ctypes.data_as(C.c_void_p)),
+               "nnmpc_qp_set_inverse")
+    assert qp.stats()["asm_e2max"] > 1e-11
+    out = qp.solve_batch(q, lb, ub)
+    st = qp.stats()
+    assert (out["status"] == 0).all(), out["status"]
+    assert st["asm_solved"] == B and st["factorizations"] == 0
+    assert st["asm_full_checks"] > 0          # the path under test was actually taken
+    nact = 0
+    for b in range(B):
+        x, act = _solve_ref(P, q[b], lb, ub, nu)
+        assert np.abs(out["u"][b] - x).max() / max(1.0, np.abs(x).max()) <= 1e-7
+        assert (out["active"][b] == act).all()
+        nact += int(act.sum())
+    assert nact > B
