@@ -294,19 +294,21 @@ __device__ __forceinline__ int asm_diag16(const double* Tk, double* Yt, int lane
   double x[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const double a = Tk[row * 17 + k];
-    x[k] = inv_half ? (k == row ? 1.0 : 0.0) : a;
+    double a = Tk[row * 17 + k];
+    asm volatile("" : "+v"(a));                            // keeps the 16 loads unconditional and back to back (the
+    x[k] = inv_half ? (k == row ? 1.0 : 0.0) : a;          // select would otherwise become 16 divergent branches)
   }
-  int bad = 0;
+  double dmin = 1.0;                                       // smallest pivot: kept beside the chain, tested once at the end
 #pragma unroll
   for (int cc = 0; cc < 16; ++cc) {
-    double dd = rdlane_d(x[cc], cc);
-    if (!(dd > 0.0)) { dd = 1.0; bad = 1; }
+    const double dd = rdlane_d(x[cc], cc);
+    dmin = fmin(dmin, dd);
     const double w = x[cc] * rsqrt(dd);                    // L[row][cc]  |  Y[cc][row]
     x[cc] = w;
 #pragma unroll
     for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] -= w * rdlane_d(w, c2);
   }
+  const int bad = !(dmin > 0.0);                           // not positive definite in fp64 (everything after it is NaN)
   if (lane >= 48) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = x[k];
@@ -498,6 +500,11 @@ __device__ __forceinline__ double xsum4(double x) {
 }
 
 __host__ __device__ constexpr int asm_tix(int I, int J) { return I * (I + 1) / 2 + J; }
+template <int V> struct asm_ic { static constexpr int value = V; };
+template <int B, int E, class F>
+__device__ __forceinline__ void asm_sfor(F&& f) {          // f(asm_ic<B>{}), ..., f(asm_ic<E-1>{}): indices are constants
+  if constexpr (B < E) { f(asm_ic<B>{}); asm_sfor<B + 1, E>(f); }
+}
 
 template <int MB>
 __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg) {
@@ -560,16 +567,38 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
 #pragma unroll
   for (int I = 0; I < MB; ++I) ps[I] = 0.0;
   int bad = 0;
-  // ---- blocked Cholesky (right-looking) with the forward substitution riding along
+  // ---- blocked Cholesky (right-looking) with the forward substitution riding along.  The diagonal step of
+  // block column K + 1 (a long dependent VALU chain) is issued right after the one tile it needs, in the same
+  // stretch of code as the rest of column K's trailing MFMAs, which do not depend on it.
+  auto trail = [&](auto Kc, auto Jc, auto Ic, const f64x4_t* P) {   // tile (I,J) += L(J,K) L(I,K)'   (accumulates -Schur)
+    constexpr int K = decltype(Kc)::value, J = decltype(Jc)::value, I = decltype(Ic)::value;
+    constexpr bool in_lds = J < NL && I > J;
+    f64x4_t acc;
+    if (in_lds) {
 #pragma unroll
-  for (int K = 0; K < MB; ++K) {
+      for (int r = 0; r < 4; ++r) acc[r] = lt[slot(I, J) * 256 + r * 64];
+    } else {
+      acc = C[asm_tix(I, J)];
+    }
+    const f64x4_t a = K < NL ? P[J] : C[asm_tix(J, K)], b = K < NL ? P[I] : C[asm_tix(I, K)];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dt[li * 17 + lq + 4 * r] = -C[asm_tix(K, K)][r];
-    ASM_FENCE();
+    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc, 0, 0, 0);
+    if (in_lds) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lt[slot(I, J) * 256 + r * 64] = acc[r];
+    } else {
+      C[asm_tix(I, J)] = acc;
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dt[li * 17 + lq + 4 * r] = -C[asm_tix(0, 0)][r];
+  ASM_FENCE();
 #ifndef DBG_NO_DIAG
-    bad |= asm_diag16(dt, Yt, lane);
+  bad |= asm_diag16(dt, Yt, lane);
 #endif
-    ASM_FENCE();
+  ASM_FENCE();
+  asm_sfor<0, MB>([&](auto Kc) {
+    constexpr int K = decltype(Kc)::value;
     __builtin_amdgcn_sched_barrier(0);
     double yf[4];                                          // fragments of -Y_K
     f64x4_t Yc;                                            // Y_K' in C layout: [li][lq + 4r] of Y' = Y[lq + 4r][li]
@@ -608,34 +637,30 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ps[I] += acc[r] * yq[r];
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K + 1 < MB) {
 #ifndef DBG_NO_TRAIL
-#pragma unroll
-    for (int J = K + 1; J < MB; ++J) {                     // trailing update, column by column (column K+1 first)
-#pragma unroll
-      for (int I = J; I < MB; ++I) {
-        const bool in_lds = J < NL && I > J;
-        f64x4_t acc;
-        if (in_lds) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = lt[slot(I, J) * 256 + r * 64];
-        } else {
-          acc = C[asm_tix(I, J)];
-        }
-        const f64x4_t a = K < NL ? P[J] : C[asm_tix(J, K)], b = K < NL ? P[I] : C[asm_tix(I, K)];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc, 0, 0, 0);
-        if (in_lds) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lt[slot(I, J) * 256 + r * 64] = acc[r];
-        } else {
-          C[asm_tix(I, J)] = acc;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+      trail(Kc, asm_ic<K + 1>{}, asm_ic<K + 1>{}, P);      // the next diagonal tile first ...
 #endif
-  }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dt[li * 17 + lq + 4 * r] = -C[asm_tix(K + 1, K + 1)][r];
+      ASM_FENCE();
+      __builtin_amdgcn_sched_barrier(0);
+      // ... then its factorisation together with the rest of the trailing update
+#ifndef DBG_NO_TRAIL
+      asm_sfor<K + 1, MB>([&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        asm_sfor<J, MB>([&](auto Ic) {
+          constexpr int I = decltype(Ic)::value;
+          if constexpr (!(I == K + 1 && J == K + 1)) trail(Kc, Jc, Ic, P);
+        });
+      });
+#endif
+#ifndef DBG_NO_DIAG
+      bad |= asm_diag16(dt, Yt, lane);
+#endif
+      ASM_FENCE();
+    }
+  });
   if (bad) { if (lane == 0) d.state[p] = ASM_FALLBACK; return; }
   ASM_FENCE();
   // ---- backward substitution  L' lam = y
