@@ -253,21 +253,28 @@ def main():
             gemm = {"kernel": "gemm_nt_f64_k (LAM * Pinv)", "bound": "mfma", "achieved": gach, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": gach / FP64_PEAK_TFLOPS, "traffic": None,
                     "launches": st["asm_gemm_launches"], "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]),
-                    "algorithmic_flops": "2 n k_max per problem still running and round (k_max = last active bound of the round)",
+                    "algorithmic_flops": "2 * (columns evaluated) * k_max per running problem and round (k_max = last active bound; columns = window past it) + one full-width pass 2 n k_max per problem",
                     "time_share": st["asm_gemm_ms"] / st["total_ms"]}
             lach = st["asm_lambda_flops"] / (st["asm_lambda_ms"] * 1e-3) / 1e12
-            lam = {"kernel": "asm_lambda_tile_k (|A|x|A| fp64 Cholesky + solves of the multiplier systems, in LDS)",
+            lam = {"kernel": "asm_lambda_reg_k (|A|x|A| fp64 Cholesky + solves of the multiplier systems: one wave per "
+                             "problem, tiles in the MFMA accumulators; sets > 144 bounds: asm_lambda_tile_k beside it)",
                    "bound": "mfma", "achieved": lach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": lach / FP64_PEAK_TFLOPS, "traffic": None,
+                   "frac": lach / FP64_PEAK_TFLOPS,
+                   # HBM bytes per launch from the PMC passes of profiles/r01e_pmc_asm.json (B = 65536): the gathered
+                   # Pinv blocks (algorithmic_GBps below) come from L2 / Infinity Cache, not from HBM
+                   "traffic": 3.12e8 if (args.workload == "cdu" and B == 65536) else None,
+                   "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01e_pmc_asm.json)",
                    "algorithmic_flops": "m^3/3 + 2 m^2 per problem and round, m = size of its active set",
                    "algorithmic_GBps": st["asm_lambda_bytes"] / (st["asm_lambda_ms"] * 1e-3) / 1e9,
+                   "launches": st["asm_rounds"], "avg_launch_ms": st["asm_lambda_ms"] / max(1, st["asm_rounds"]),
                    "time_share": st["asm_lambda_ms"] / st["total_ms"],
-                   "note": "latency-bound: ~100-200 variables per system, a chain of 16 x 16 tile steps per problem; "
-                           "HBM traffic ~0.04 TB/s (Pinv stays in L2/MALL), see profiles/"}
+                   "note": "latency-bound, not throughput-bound: per problem a chain of |A| dependent pivot steps "
+                           "(16 x 16 diagonal tiles on the VALU) between the MFMA tile updates; 1024 problems in flight"}
             first, second = (lam, gemm) if st["asm_lambda_ms"] >= st["asm_gemm_ms"] else (gemm, lam)
             out["roofline"] = first
             out["roofline_secondary"] = second
-            out["roofline"]["other_time_share"] = {"asm_update": st["asm_update_ms"] / st["total_ms"]}
+            out["roofline"]["other_time_share"] = {"set_bookkeeping_kernels": st["asm_update_ms"] / st["total_ms"]}
+            out["solver"]["checked_with_P_itself"] = int(st["asm_full_checks"])
             out["solver"]["inverse_check"] = {"max_abs_P_Pinv_minus_I": st["asm_e2max"], "max_abs_P_Kunc_plus_tq": st["asm_e1max"]}
         else:
             out["roofline"] = panel_roofline(st)

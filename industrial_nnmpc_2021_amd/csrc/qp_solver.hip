@@ -833,7 +833,10 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   const int segp = ((nprob + 127) / 128) * 128;
   hipLaunchKernelGGL(pad_x0_k, dim3(512), dim3(256), 0, s, h->x0_64, h->x0_32, x0_dev, nprob, h->n_aug, h->ka, segp);
   // x_unc = Kunc x0 for the whole segment; q = tq x0 is only formed for the rows that need the full check with P
-  gemm64(h, h->asm_xunc, h->np, h->x0_64, h->ka, h->Kunc64, h->ka, segp, h->np, h->ka);
+  {
+    EvScope es(h, 5, 2.0 * h->np * (double)h->ka * nprob);
+    gemm64(h, h->asm_xunc, h->np, h->x0_64, h->ka, h->Kunc64, h->ka, segp, h->np, h->ka);
+  }
   AsmDev a;
   a.n = h->n; a.np = h->np; a.nu = h->nu; a.nseg = nprob;
   a.max_active = h->opts.asm_max_active; a.max_rounds = h->opts.asm_max_rounds;
