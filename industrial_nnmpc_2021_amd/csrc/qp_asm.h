@@ -27,7 +27,7 @@ constexpr int ASM_MLDS = 176;      // largest active set factored in LDS (11 x 1
 constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: conflict-free MFMA operand reads)
 enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4 };   // CERT: finished and certified by the inverse-error bound
 constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
-constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds) run the register kernel, the others the LDS-tile kernel
+constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds): four problems per workgroup (asm_lambda_reg_k); 6, 7: two
 constexpr int ASM_NCNT = 16;       // ints in AsmDev::counters
 constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check ([13]: handled by the last asm_wide_k)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
@@ -463,11 +463,12 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
 // and its inverse (columns on lanes -> fragments): two fences per block column.  Both substitutions
 // stay in registers: sums over a tile row are DPP reductions inside the 16-lane rows, sums over the
 // four lane rows use v_permlane16/32_swap.
-// The 512 registers of a wave hold 32 tiles next to the working set; for MB = 8, 9 the strictly lower
-// tiles of the first NL = 2 block columns -- touched by one TRSM, one pass as operands and the backward
-// substitution only -- live in LDS instead (C layout, 2 KB each).
-__host__ __device__ constexpr int asm_nl(int mb) { return mb <= 7 ? 0 : 2; }
-__host__ __device__ constexpr int asm_nlt(int mb) { return asm_nl(mb) == 0 ? 0 : (asm_nl(mb) == 1 ? mb - 1 : 2 * mb - 3); }
+// The 512 registers of a wave hold 32 tiles next to the working set; for MB = 8, 9 (10, 11) the strictly
+// lower tiles of the first NL = 2 (4) block columns -- touched by one TRSM, one pass as operands and the
+// backward substitution only -- live in LDS instead (C layout, 2 KB each).  10- and 11-block sets then need
+// ~70 KB of LDS per wave: two waves per workgroup (asm_lambda_reg2_k).
+__host__ __device__ constexpr int asm_nl(int mb) { return mb <= 7 ? 0 : (mb <= 9 ? 2 : 4); }
+__host__ __device__ constexpr int asm_nlt(int mb) { return asm_nl(mb) * (mb - 1) - asm_nl(mb) * (asm_nl(mb) - 1) / 2; }
 __host__ __device__ constexpr int asm_rw(int mb) { return 2 * ASM_TS + 2 * mb * 16 + asm_nlt(mb) * 256; }   // doubles of LDS per wave
 
 template <int CTRL>
@@ -506,7 +507,7 @@ __device__ __forceinline__ void asm_sfor(F&& f) {          // f(asm_ic<B>{}), ..
   if constexpr (B < E) { f(asm_ic<B>{}); asm_sfor<B + 1, E>(f); }
 }
 
-template <int MB>
+template <int MB, int WPB>
 __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg) {
   constexpr int NL = asm_nl(MB);
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -517,9 +518,9 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
   double* ys = Yt + ASM_TS;                                // y (forward result), [MB][16]
   double* rv = ys + MB * 16;                               // right-hand side, [MB][16]
   double* lt = rv + MB * 16 + lane;                        // LDS-resident tiles: slot * 256 + r * 64 (+ lane)
-  auto slot = [](int I, int J) { return J == 0 ? I - 1 : MB - 1 + I - 2; };   // tile (I,J), J < NL, I > J
+  auto slot = [](int I, int J) { return J * (MB - 1) - J * (J - 1) / 2 + I - J - 1; };   // tile (I,J), J < NL, I > J
   const int nitem = d.counters[4 + bin];
-  const int it = wg * 4 + wave;
+  const int it = wg * WPB + wave;
   if (it >= nitem) return;
   const int p = __builtin_amdgcn_readfirstlane(d.binlist[(size_t)bin * d.nseg + it]);
   const size_t o = (size_t)p * d.np;
@@ -699,12 +700,24 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
 #define ASM_REG_CLASS(B)                                                   \
   {                                                                        \
     const int nb = (d.counters[4 + B] + 3) >> 2;                           \
-    if (w < nb) { asm_lambda_reg<B + 4>(d, B, w); return; }                \
+    if (w < nb) { asm_lambda_reg<B + 4, 4>(d, B, w); return; }             \
     w -= nb;                                                               \
   }
   ASM_REG_CLASS(5) ASM_REG_CLASS(4) ASM_REG_CLASS(3) ASM_REG_CLASS(2) ASM_REG_CLASS(1) ASM_REG_CLASS(0)
 #undef ASM_REG_CLASS
   static_assert(ASM_NREG == 6, "one ASM_REG_CLASS line per register-resident size class");
+}
+// The 10- and 11-block classes (145..176 bounds): same code, two waves (problems) per workgroup.
+constexpr int ASM_REG2_LDS = 2 * asm_rw(11) * 8;
+__global__ __launch_bounds__(128, 1) void asm_lambda_reg2_k(AsmDev d) {
+  int w = blockIdx.x;
+  {
+    const int nb = (d.counters[4 + 7] + 1) >> 1;
+    if (w < nb) { asm_lambda_reg<11, 2>(d, 7, w); return; }
+    w -= nb;
+  }
+  asm_lambda_reg<10, 2>(d, 6, w);
+  static_assert(ASM_NBIN == 8 && ASM_MLDS == 176, "classes 6 and 7 are the 10- and 11-block sets");
 }
 
 // x from the GEMM result, fp64 KKT tests, next active set.  A problem whose set no longer changes

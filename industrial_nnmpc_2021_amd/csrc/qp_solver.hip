@@ -887,21 +887,16 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     a.W = std::min(h->np, ((cnt[3] + 1 + 4 * h->nu + 63) / 64) * 64);
     {
       EvScope es(h, 4, 0.0);
-      // size classes 0..ASM_NREG-1 (<= 144 bounds): one wave per problem, S in registers, one launch.  The
-      // few larger sets (one workgroup per problem, tiles in LDS or in an L2 slab) are long latency chains
-      // on a handful of CUs: they run beside it on the side stream.
-      int nbig = cnt[1], nreg_wg = 0;
-      for (int b = ASM_NREG; b < ASM_NBIN; ++b) nbig += cnt[4 + b];
+      // one wave per problem, S in registers: size classes 0..5 (<= 144 bounds) in one launch, four problems per
+      // workgroup; classes 6, 7 (<= 176) two per workgroup and the rare larger sets (tiles in an L2 slab, one
+      // workgroup each: long latency chains on a handful of CUs) beside it on the side stream.
+      const int nreg2_wg = (cnt[4 + 6] + 1) / 2 + (cnt[4 + 7] + 1) / 2;
+      int nbig = cnt[1] + nreg2_wg, nreg_wg = 0;
       for (int b = 0; b < ASM_NREG; ++b) nreg_wg += (cnt[4 + b] + 3) / 4;
       if (nbig) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        for (int b = ASM_NREG; b < ASM_NBIN; ++b) {
-          if (cnt[4 + b] == 0) continue;
-          const int mbc = asm_bin_cap(b) / 16;
-          const int lds = (asm_bin_cap(b) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
-          hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(cnt[4 + b]), dim3(256), lds, h->stream2, a, b);
-        }
+        if (nreg2_wg) hipLaunchKernelGGL(asm_lambda_reg2_k, dim3(nreg2_wg), dim3(128), ASM_REG2_LDS, h->stream2, a);
         if (cnt[1]) hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream2, a, 0);
         HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       }
@@ -1033,9 +1028,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     set_error("hipStreamCreate / hipEventCreate failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP;
   }
   {
-    hipError_t e = hipFuncSetAttribute((const void*)asm_lambda_tile_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (ASM_MLDS + ASM_TS + (ASM_MLDS / 16) * (ASM_MLDS / 16 + 1) / 2 * ASM_TS) * 8);
+    hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
   if (set_lds_attrs<128>() != 0 || set_lds_attrs<64>() != 0) {

@@ -62,13 +62,15 @@ int main(int argc, char** argv) {
   const int lds_tile = (asm_bin_cap(bin) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
   CK(hipFuncSetAttribute((const void*)asm_lambda_tile_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (ASM_MLDS + ASM_TS + 66 * ASM_TS) * 8));
   CK(hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS));
+  CK(hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
     if (variant == 0) hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nseg), dim3(256), lds_tile, 0, d, bin);
     else {
-      hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, 0, d);
+      if (bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, 0, d);
+      else hipLaunchKernelGGL(asm_lambda_reg2_k, dim3((nseg + 1) / 2 + 2), dim3(128), ASM_REG2_LDS, 0, d);
     }
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) best = std::min(best, ms);
