@@ -705,6 +705,11 @@ void gemm32(nnmpc_qp* h, float* C, size_t ldc, const float* A, size_t lda, const
 void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, const double* B,
             size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0,
             const int* kdyn = nullptr, const int* mdyn = nullptr) {
+  if (M % 128 == 0 && N % 128 == 0) {
+    hipLaunchKernelGGL(gemm_nt_f64_128_k, dim3(N / 128, M / 128), dim3(256), GEMM64_128_LDS, h->stream, C, ldc, A, lda, B, ldb, K,
+                       rowphase, want, kdyn, mdyn);
+    return;
+  }
   dim3 grid(N / 64, M / 64);
   hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want, kdyn, mdyn);
 }
@@ -862,7 +867,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // problems that settled inside last round's column window: all columns of x, once
       {
         EvScope es(h, 5, 0.0);
-        gemm64(h, h->asm_xhw, h->np, h->asm_lamw, h->np, h->H64, h->np, ((prev_run + 63) / 64) * 64, h->np, h->np, nullptr, 0,
+        gemm64(h, h->asm_xhw, h->np, h->asm_lamw, h->np, h->H64, h->np, ((prev_run + 127) / 128) * 128, h->np, h->np, nullptr, 0,
                h->asm_counters + 3, h->asm_counters + ASM_CNT_WIDE);
       }
       EvScope es(h, 6, 0.0);
@@ -884,7 +889,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     h->stats.asm_rounds += 1;
     // column window of this round: past the last active bound of any running problem plus four stages; a
     // problem that settles inside it gets one full-width pass (asm_wide_k) at the start of the next round
-    a.W = std::min(h->np, ((cnt[3] + 1 + 4 * h->nu + 63) / 64) * 64);
+    a.W = std::min(h->np, ((cnt[3] + 1 + 4 * h->nu + 127) / 128) * 128);
     {
       EvScope es(h, 4, 0.0);
       // one wave per problem, S in registers: size classes 0..5 (<= 144 bounds) in one launch, four problems per
@@ -907,7 +912,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // the running problems sit in rows 0..nrun-1 of LAM (asm_bins_k), the rest of the last 64-row block is zero;
       // algorithmic flops of LAM * Pinv: 2 * n * (columns up to the last active bound) per running problem
       EvScope es(h, 5, 2.0 * a.W * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun);
-      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((nrun + 63) / 64) * 64, a.W, h->np, nullptr, 0,
+      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((nrun + 127) / 128) * 128, a.W, h->np, nullptr, 0,
              h->asm_counters + 3);
     }
     {
@@ -1031,6 +1036,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
   if (set_lds_attrs<128>() != 0 || set_lds_attrs<64>() != 0) {
