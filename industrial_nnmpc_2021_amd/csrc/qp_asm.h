@@ -727,18 +727,16 @@ __global__ __launch_bounds__(128, 1) void asm_lambda_reg2_k(AsmDev d) {
 // so |stationarity residual on the free set| <= e1max |x0|_1 + e2max |lam|_1 =: bnd, and the
 // multiplier signs are certain when every |lam_a| > bnd.  Otherwise (ASM_DONE) the full check
 // with P itself (asm_certify_k) decides.
-__global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
-  __shared__ int cnt[4];
-  __shared__ double red[12];
-  __shared__ int s_wrow;
-  const int p = blockIdx.x, tid = threadIdx.x;
-  if (d.state[p] != ASM_RUN) return;
+__global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE per problem: the window is a few hundred columns
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= d.nseg || d.state[p] != ASM_RUN) return;
   const size_t o = (size_t)p * d.np, orow = (size_t)d.row[p] * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
   const int W = min(d.W, d.n);                               // every active bound lies inside the window
   int chg = 0;
   double l1 = 0.0, lmin = 1e300;
-  for (int r = tid; r < W; r += 256) {
+  for (int r = lane; r < W; r += 64) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     const int s = st[r];
@@ -752,50 +750,46 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {
       if ((s == 1 && l <= 0.0) || (s == 2 && l >= 0.0)) { st[r] = 0; ++chg; }   // keep iff multiplier > 0
     }
   }
-  double x1 = 0.0;
-  for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
-  for (int off = 32; off > 0; off >>= 1) {
-    chg += __shfl_xor(chg, off);
-    l1 += __shfl_xor(l1, off); x1 += __shfl_xor(x1, off);
-    lmin = fmin(lmin, __shfl_xor(lmin, off));
-  }
-  if ((tid & 63) == 0) {
-    const int w = tid >> 6;
-    cnt[w] = chg; red[w] = l1; red[4 + w] = x1; red[8 + w] = lmin;
-  }
-  __syncthreads();
-  const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  for (int off = 32; off > 0; off >>= 1) chg += __shfl_xor(chg, off);
+  const int tot = chg;
   const bool settle_wide = tot == 0 && W < d.n;              // settled inside the window: full-width check next
-  if (settle_wide && tid == 0) {
-    const int w = atomicAdd(&d.counters[ASM_CNT_WIDE], 1);   // once per problem (and re-entry), not per round
-    d.wlist[w] = p;
-    s_wrow = w;
+  int wrow = 0;
+  if (settle_wide) {
+    if (lane == 0) {
+      wrow = atomicAdd(&d.counters[ASM_CNT_WIDE], 1);        // once per problem (and re-entry), not per round
+      d.wlist[wrow] = p;
+    }
+    wrow = __shfl(wrow, 0);
   }
-  __syncthreads();
   // the LAM row goes back to zero (rows are handed out anew every round); a settled problem takes its
   // multipliers along into its row of LAMW
   {
-    double* lw = settle_wide ? d.lamw + (size_t)s_wrow * d.np : nullptr;
-    for (int r = tid; r < W; r += 256) {
+    double* lw = settle_wide ? d.lamw + (size_t)wrow * d.np : nullptr;
+    for (int r = lane; r < W; r += 64) {
       const double l = d.lam[orow + r];
       if (l != 0.0) { d.lam[orow + r] = 0.0; if (lw) lw[r] = l; }
     }
   }
-  const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
-  const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
-  const double QI = d.tqmax * X1;                            // >= |q|_inf
-  const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
-  const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
-  if (tot == 0 && !settle_wide) {                            // finished: only now x is written out, straight into the
-    for (int r = tid; r < d.n; r += 256) {                   // caller's buffer (and as a GEMM row if P must confirm it)
+  bool sure = false;
+  if (tot == 0 && !settle_wide) {                            // finished (window = all columns): certificate, and only
+    double x1 = 0.0;                                         // now x is written out, straight into the caller's buffer
+    for (int k = lane; k < d.ka; k += 64) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
+    for (int off = 32; off > 0; off >>= 1) {
+      l1 += __shfl_xor(l1, off); x1 += __shfl_xor(x1, off);
+      lmin = fmin(lmin, __shfl_xor(lmin, off));
+    }
+    const double QI = d.tqmax * x1;                          // >= |q|_inf
+    const double bnd = 2.0 * (d.e1max * x1 + d.e2max * l1) + 1e-14 * (QI + l1);
+    sure = bnd <= d.stat_tol * d.pscale && lmin > bnd;
+    for (int r = lane; r < d.n; r += 64) {
       const int k = r % d.nu, s = st[r];
       const double x = s == 0 ? d.xunc[o + r] - d.xh[orow + r]
                               : (s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
       d.u_out[(size_t)p * d.n + r] = x;
-      if (!sure) d.x[o + r] = x;
+      if (!sure) d.x[o + r] = x;                             // as a GEMM row too if P itself must confirm it
     }
   }
-  if (tid == 0) {
+  if (lane == 0) {
     const int rd = d.rounds[p] + 1;
     d.rounds[p] = rd;
     if (settle_wide) d.state[p] = ASM_WIDE;

@@ -917,7 +917,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
     {
       EvScope es(h, 6, 0.0);
-      hipLaunchKernelGGL(asm_update_k, dim3(nprob), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(asm_update_k, dim3((nprob + 3) / 4), dim3(256), 0, s, a);
     }
     prev_run = a.W < h->n ? nrun : 0;
   }
