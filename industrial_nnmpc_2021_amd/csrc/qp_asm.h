@@ -28,10 +28,15 @@ constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: 
 enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4 };   // CERT: finished and certified by the inverse-error bound
 constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
 constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds): four problems per workgroup (asm_lambda_reg_k); 6, 7: two
-constexpr int ASM_NCNT = 16;       // ints in AsmDev::counters
+constexpr int ASM_NCNT = 24;       // ints in AsmDev::counters
+constexpr int ASM_CNT_F32 = 16;    // counters[16 + b]: length of the f32 list of size class b < ASM_NREG
+constexpr int ASM_NLIST = ASM_NBIN + ASM_NREG;   // lists in AsmDev::binlist: fp64 classes, then f32 classes
 constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check ([13]: handled by the last asm_wide_k)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
-constexpr int ASM_NSCAN = ASM_NBIN + 3;   // scan columns: running, large sets, size classes, max active index
+// list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
+// ASM_NBIN + b (b < ASM_NREG) the f32 ones (counters[ASM_CNT_F32 + b])
+__host__ __device__ constexpr int asm_list_counter(int list) { return list < ASM_NBIN ? 4 + list : ASM_CNT_F32 + list - ASM_NBIN; }
+constexpr int ASM_NSCAN = ASM_NLIST + 3;  // scan columns: running, large sets, the lists, max active index
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
 
 struct AsmDev {
@@ -64,8 +69,11 @@ struct AsmDev {
   int* row;                        // [nseg] row of lam / xh this round: the running problems are packed into rows
                                    // 0..nrun-1 (counters[2]), so the GEMM only covers those
   double tqmax;                    // max |tq| entry: |q|_inf <= tqmax |x0|_1 (q itself is only formed for the full check)
+  unsigned char* prec;             // [nseg] 0: rounds in f32 until the set settles, 1: fp64 (only these results are accepted)
+  unsigned char* redo;             // [nseg] set by the f32 kernel when S is not positive definite in f32: the round is void
   int* lrank;                      // [nseg] asm_bins scratch: rank inside its chunk and list
   int* ctot;                       // [chunks][ASM_NSCAN] asm_bins scratch: per-chunk totals, last column: max active index
+  int use_f32;                     // run the rounds in f32 until the set settles (then fp64)
   int W;                           // columns evaluated in this round (multiple of 64, past the last active bound of any
                                    // running problem + a margin); W < n: a problem that settles inside the window is
                                    // handed to the full-width check (asm_wide_k) through the lists below
@@ -101,7 +109,11 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     d.st[(size_t)p * d.n + r] = (unsigned char)s;
   }
   // an empty set runs one round like the others: x = x_unc is checked and certified by asm_update_k / asm_wide_k
-  if (tid == 0) { d.rounds[p] = 0; d.state[p] = ASM_RUN; }
+  if (tid == 0) {
+    d.rounds[p] = 0; d.state[p] = ASM_RUN;
+    d.prec[p] = (d.use_f32 && !d.guess) ? 0 : 1;       // a caller's guess is expected to be right: confirm it in fp64 at once
+    d.redo[p] = 0;
+  }
 }
 
 // Round stage 0a: ordered list of the active indices of every running problem and its length.
@@ -164,11 +176,13 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // counters: [0] = [2] = nrun, [1] sets too large for LDS, [3] largest active variable index, [4 + b] length
 // of size-class list b.  counters[ASM_CNT_WIDE] (filled by asm_update_k, consumed by asm_wide_k earlier in
 // the round) is reset here.
-__device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + b size class b
+__device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + list otherwise
   run = p < d.nseg && d.state[p] == ASM_RUN;
   if (!run) return -1;
   const int m = d.mg[p];
-  return m > ASM_MLDS ? 0 : 1 + max((m + 15) / 16, 4) - 4;
+  if (m > ASM_MLDS) return 0;
+  const int b = max((m + 15) / 16, 4) - 4;
+  return 1 + ((d.prec[p] == 0 && b < ASM_NREG) ? ASM_NBIN + b : b);
 }
 __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   __shared__ int wtot[ASM_NSCAN][16];
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
     if (lane == 0) wtot[0][wave] = __popcll(mk);
   }
 #pragma unroll
-  for (int c = 0; c <= ASM_NBIN; ++c) {
+  for (int c = 0; c <= ASM_NLIST; ++c) {
     const unsigned long long mk = __ballot(col == c);
     if (col == c) myrank = __popcll(mk & lt);
     if (lane == 0) wtot[1 + c][wave] = __popcll(mk);
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
         const int tot = t + d.ctot[(size_t)blockIdx.x * ASM_NSCAN + tid];
         if (tid == 0) { d.counters[0] = tot; d.counters[2] = tot; }
         else if (tid == 1) d.counters[1] = tot;
-        else d.counters[4 + tid - 2] = tot;
+        else d.counters[asm_list_counter(tid - 2)] = tot;
       }
     }
   }
@@ -281,42 +295,8 @@ __device__ __forceinline__ double bcast16(double x, int l) {   // l: compile-tim
   }
 }
 
-// 16 x 16 diagonal tile: Cholesky L and Y = L^-1 in one sweep of 16 column steps, no LDS traffic in
-// the chain.  Lanes 0..31 (two mirrored 16-lane rows) hold the rows of the tile, lanes 32..63 the
-// columns of Y (lane 32 + j: Y[.][j], starting from e_j): with w = x[cc] / L[cc][cc] both halves run
-// the SAME update  x[c2] -= w * L[c2][cc]  -- it is the elimination step for the first half and the
-// forward substitution L Y = I for the second.  Pivot and L[c2][cc] are wave-uniform (v_readlane from
-// lanes cc / c2), used once each, so they do not pile up in SGPRs.  16 live doubles per lane.
-// Tk: the tile in LDS (row-major, stride 17, read only); Yt receives Y (same layout).
-__device__ __forceinline__ int asm_diag16(const double* Tk, double* Yt, int lane) {
-  const int row = lane & 15;
-  const bool inv_half = lane >= 32;
-  double x[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    double a = Tk[row * 17 + k];
-    asm volatile("" : "+v"(a));                            // keeps the 16 loads unconditional and back to back (the
-    x[k] = inv_half ? (k == row ? 1.0 : 0.0) : a;          // select would otherwise become 16 divergent branches)
-  }
-  double dmin = 1.0;                                       // smallest pivot: kept beside the chain, tested once at the end
-#pragma unroll
-  for (int cc = 0; cc < 16; ++cc) {
-    const double dd = rdlane_d(x[cc], cc);
-    dmin = fmin(dmin, dd);
-    const double w = x[cc] * rsqrt(dd);                    // L[row][cc]  |  Y[cc][row]
-    x[cc] = w;
-#pragma unroll
-    for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] -= w * rdlane_d(w, c2);
-  }
-  const int bad = !(dmin > 0.0);                           // not positive definite in fp64 (everything after it is NaN)
-  if (lane >= 48) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = x[k];
-  }
-  return bad;
-}
-
-__device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane) { return asm_diag16(Tk, Yt, lane); }
+template <class T> __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane);
+__device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane);
 
 template <int BIG>
 __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
@@ -446,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
   }
   __syncthreads();
   {
+    if (tid == 0) d.prec[p] = 1;                               // an fp64 solve
     double* lrow = d.lam + (size_t)d.row[p] * d.np;
     for (int i = tid; i < m; i += 256) lrow[idx[i]] = rA[i];        // the rest of the row is zero (asm_update_k)
   }
@@ -467,38 +448,78 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
 // lower tiles of the first NL = 2 (4) block columns -- touched by one TRSM, one pass as operands and the
 // backward substitution only -- live in LDS instead (C layout, 2 KB each).  10- and 11-block sets then need
 // ~70 KB of LDS per wave: two waves per workgroup (asm_lambda_reg2_k).
-__host__ __device__ constexpr int asm_nl(int mb) { return mb <= 7 ? 0 : (mb <= 9 ? 2 : 4); }
-__host__ __device__ constexpr int asm_nlt(int mb) { return asm_nl(mb) * (mb - 1) - asm_nl(mb) * (asm_nl(mb) - 1) / 2; }
-__host__ __device__ constexpr int asm_rw(int mb) { return 2 * ASM_TS + 2 * mb * 16 + asm_nlt(mb) * 256; }   // doubles of LDS per wave
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_d(double x) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
+//
+// The same code runs in f32 (AsmNum<float>, v_mfma_f32_16x16x4_f32): tiles take half the registers, so two
+// waves share a SIMD and hide each other's pivot chains, and the chain itself is shorter (one v_readlane
+// per broadcast, v_rsq_f32 without refinement).  f32 multipliers are good to ~cond(S) * 6e-8 -- enough to
+// decide which bounds to add or drop, not to deliver them: a problem runs its rounds in f32 until its set
+// settles, then in fp64 (prec[p]) until it settles again, and only fp64 results are ever accepted.
+template <class T> struct AsmNum;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <> struct AsmNum<double> {
+  using v4 = f64x4_t;
+  static constexpr bool F32 = false;
+  // C/D layout of v_mfma_f64_16x16x4_f64: reg r of lane (li, lq) is row lq + 4r, column li
+  __host__ __device__ static constexpr int kr(int lq, int r) { return lq + 4 * r; }
+  __device__ static __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ double rdlane(double x, int l) { return rdlane_d(x, l); }
+  __device__ static __forceinline__ double rsq(double x) { return rsqrt(x); }
+  template <int CTRL> __device__ static __forceinline__ double dpp(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+  __device__ static __forceinline__ double swap16(double x) {   // x[l] + x[l ^ 16]
+    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  __device__ static __forceinline__ double swap32(double x) {   // x[l] + x[l ^ 32]
+    const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+};
+template <> struct AsmNum<float> {
+  using v4 = f32x4_t;
+  static constexpr bool F32 = true;
+  // C/D layout of v_mfma_f32_16x16x4_f32: reg r of lane (li, lq) is row 4 lq + r, column li.  The k index a
+  // register stands for only has to be the same for both operands of an MFMA, which it is: both come from
+  // accumulators (or from fragments read with the same kr()).
+  __host__ __device__ static constexpr int kr(int lq, int r) { return 4 * lq + r; }
+  __device__ static __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+  __device__ static __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+  template <int CTRL> __device__ static __forceinline__ float dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, false));
+  }
+  __device__ static __forceinline__ float swap16(float x) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(x), false, false);
+    return __int_as_float(a[0]) + __int_as_float(a[1]);
+  }
+  __device__ static __forceinline__ float swap32(float x) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_int(x), __float_as_int(x), false, false);
+    return __int_as_float(a[0]) + __int_as_float(a[1]);
+  }
+};
 // sum over the 16 lanes of a lane row, result in every lane of the row
-__device__ __forceinline__ double rowsum16(double x) {
-  x += dpp_mov_d<0xB1>(x);        // quad_perm [1,0,3,2]
-  x += dpp_mov_d<0x4E>(x);        // quad_perm [2,3,0,1]
-  x += dpp_mov_d<0x141>(x);       // row_half_mirror
-  x += dpp_mov_d<0x140>(x);       // row_mirror
+template <class T> __device__ __forceinline__ T rowsum16(T x) {
+  using N = AsmNum<T>;
+  x += N::template dpp<0xB1>(x);        // quad_perm [1,0,3,2]
+  x += N::template dpp<0x4E>(x);        // quad_perm [2,3,0,1]
+  x += N::template dpp<0x141>(x);       // row_half_mirror
+  x += N::template dpp<0x140>(x);       // row_mirror
   return x;
 }
 // sum over the four lane rows (lanes l, l^16, l^32, l^48), result in all of them
-__device__ __forceinline__ double xsum4(double x) {
-  {
-    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(x), false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(x), false, false);
-    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  }
-  {
-    const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(x), false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(x), false, false);
-    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  }
-  return x;
+template <class T> __device__ __forceinline__ T xsum4(T x) { return AsmNum<T>::swap32(AsmNum<T>::swap16(x)); }
+
+// tiles of the first NL block columns kept in LDS; LDS elements per wave
+template <class T> __host__ __device__ constexpr int asm_nl(int mb) {
+  return AsmNum<T>::F32 ? (mb <= 7 ? 0 : 2) : (mb <= 7 ? 0 : (mb <= 9 ? 2 : 4));
 }
+template <class T> __host__ __device__ constexpr int asm_nlt(int mb) { return asm_nl<T>(mb) * (mb - 1) - asm_nl<T>(mb) * (asm_nl<T>(mb) - 1) / 2; }
+template <class T> __host__ __device__ constexpr int asm_rw(int mb) { return 2 * ASM_TS + 2 * mb * 16 + asm_nlt<T>(mb) * 256; }
 
 __host__ __device__ constexpr int asm_tix(int I, int J) { return I * (I + 1) / 2 + J; }
 template <int V> struct asm_ic { static constexpr int value = V; };
@@ -507,22 +528,64 @@ __device__ __forceinline__ void asm_sfor(F&& f) {          // f(asm_ic<B>{}), ..
   if constexpr (B < E) { f(asm_ic<B>{}); asm_sfor<B + 1, E>(f); }
 }
 
-template <int MB, int WPB>
-__device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg) {
-  constexpr int NL = asm_nl(MB);
-  extern __shared__ __attribute__((aligned(16))) double sm[];
+// 16 x 16 diagonal tile: Cholesky L and Y = L^-1 in one sweep of 16 column steps, no LDS traffic in
+// the chain.  Lanes 0..31 (two mirrored 16-lane rows) hold the rows of the tile, lanes 32..63 the
+// columns of Y (lane 32 + j: Y[.][j], starting from e_j): with w = x[cc] / L[cc][cc] both halves run
+// the SAME update  x[c2] -= w * L[c2][cc]  -- it is the elimination step for the first half and the
+// forward substitution L Y = I for the second.  Pivot and L[c2][cc] are wave-uniform (v_readlane from
+// lanes cc / c2), used once each, so they do not pile up in SGPRs.  16 live values per lane.
+// Tk: the tile in LDS (row-major, stride 17, read only); Yt receives Y (same layout).
+template <class T>
+__device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane) {
+  using N = AsmNum<T>;
+  const int row = lane & 15;
+  const bool inv_half = lane >= 32;
+  T x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    T a = Tk[row * 17 + k];
+    asm volatile("" : "+v"(a));                            // keeps the 16 loads unconditional and back to back (the
+    x[k] = inv_half ? (k == row ? T(1) : T(0)) : a;        // select would otherwise become 16 divergent branches)
+  }
+  T dmin = T(1);                                           // smallest pivot: kept beside the chain, tested once at the end
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) {
+    const T dd = N::rdlane(x[cc], cc);
+    dmin = dd < dmin ? dd : dmin;
+    const T w = x[cc] * N::rsq(dd);                        // L[row][cc]  |  Y[cc][row]
+    x[cc] = w;
+#pragma unroll
+    for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] -= w * N::rdlane(w, c2);
+  }
+  const int bad = !(dmin > T(0));                          // not positive definite in this precision (the rest is NaN)
+  if (lane >= 48) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = x[k];
+  }
+  return bad;
+}
+
+__device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane) { return asm_diag16<double>(Tk, Yt, lane); }
+
+
+template <class T, int MB, int WPB>
+__device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg) {
+  using N = AsmNum<T>;
+  using V4 = typename N::v4;
+  constexpr int NL = asm_nl<T>(MB);
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  double* dt = sm + (size_t)wave * asm_rw(MB);             // diagonal tile, row-major stride 17
-  double* Yt = dt + ASM_TS;                                // its inverse factor
-  double* ys = Yt + ASM_TS;                                // y (forward result), [MB][16]
-  double* rv = ys + MB * 16;                               // right-hand side, [MB][16]
-  double* lt = rv + MB * 16 + lane;                        // LDS-resident tiles: slot * 256 + r * 64 (+ lane)
+  T* dt = reinterpret_cast<T*>(sm_raw) + (size_t)wave * asm_rw<T>(MB);   // diagonal tile, row-major stride 17
+  T* Yt = dt + ASM_TS;                                     // its inverse factor
+  T* ys = Yt + ASM_TS;                                     // y (forward result), [MB][16]
+  T* rv = ys + MB * 16;                                    // right-hand side, [MB][16]
+  T* lt = rv + MB * 16 + lane;                             // LDS-resident tiles: slot * 256 + r * 64 (+ lane)
   auto slot = [](int I, int J) { return J * (MB - 1) - J * (J - 1) / 2 + I - J - 1; };   // tile (I,J), J < NL, I > J
-  const int nitem = d.counters[4 + bin];
+  const int nitem = d.counters[asm_list_counter(list)];
   const int it = wg * WPB + wave;
   if (it >= nitem) return;
-  const int p = __builtin_amdgcn_readfirstlane(d.binlist[(size_t)bin * d.nseg + it]);
+  const int p = __builtin_amdgcn_readfirstlane(d.binlist[(size_t)list * d.nseg + it]);
   const size_t o = (size_t)p * d.np;
   const unsigned char* st = d.st + (size_t)p * d.n;
   const int* idx = d.idxg + (size_t)p * d.max_active;
@@ -532,12 +595,12 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
   for (int i = lane; i < MB * 16; i += 64) {
     const int a = idx[min(i, m - 1)], k = a % d.nu;
     const double v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
-    rv[i] = i < m ? v : 0.0;
+    rv[i] = i < m ? (T)v : T(0);
   }
-  // ---- gather: t(I,J)[r] = -S[16 I + li][16 J + lq + 4 r], read as Pinv[row of (J, lq, r)][col of (I, li)].
+  // ---- gather: t(I,J)[r] = -S[16 I + li][16 J + kr(lq, r)], read as Pinv[row of (J, lq, r)][col of (I, li)].
   // The not yet factored tiles hold MINUS the Schur complement, so the trailing update is a plain
-  // accumulation (fp64 MFMA has no negate modifier; a VALU negation would cost a pass over the operands).
-  f64x4_t C[MB * (MB + 1) / 2];
+  // accumulation (the MFMAs have no negate modifier; a VALU negation would cost a pass over the operands).
+  V4 C[MB * (MB + 1) / 2];
   {
     int gcol[MB];                                          // Pinv index of active bound 16 I + li
 #pragma unroll
@@ -546,7 +609,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
     for (int J = 0; J < MB; ++J) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gj = 16 * J + lq + 4 * r;
+        const int gj = 16 * J + N::kr(lq, r);
         const double* Hr = d.H + (size_t)idx[min(gj, m - 1)] * d.np;
 #pragma unroll
         for (int I = J; I < MB; ++I) {                     // unconditional (clamped) loads, then select
@@ -556,7 +619,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
 #else
           const double v = Hr[gcol[I]];
 #endif
-          const double e = (gi < m && gj < m) ? -v : (gi == gj ? -1.0 : 0.0);
+          const T e = (gi < m && gj < m) ? (T)(-v) : (gi == gj ? T(-1) : T(0));
           if (J < NL && I > J) lt[slot(I, J) * 256 + r * 64] = e;
           else C[asm_tix(I, J)][r] = e;
         }
@@ -564,26 +627,26 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  double ps[MB];                                           // lane-local partial sums of  sum_J L(I,J) y_J
+  T ps[MB];                                                // lane-local partial sums of  sum_J L(I,J) y_J
 #pragma unroll
-  for (int I = 0; I < MB; ++I) ps[I] = 0.0;
+  for (int I = 0; I < MB; ++I) ps[I] = T(0);
   int bad = 0;
   // ---- blocked Cholesky (right-looking) with the forward substitution riding along.  The diagonal step of
   // block column K + 1 (a long dependent VALU chain) is issued right after the one tile it needs, in the same
   // stretch of code as the rest of column K's trailing MFMAs, which do not depend on it.
-  auto trail = [&](auto Kc, auto Jc, auto Ic, const f64x4_t* P) {   // tile (I,J) += L(J,K) L(I,K)'   (accumulates -Schur)
+  auto trail = [&](auto Kc, auto Jc, auto Ic, const V4* P) {   // tile (I,J) += L(J,K) L(I,K)'   (accumulates -Schur)
     constexpr int K = decltype(Kc)::value, J = decltype(Jc)::value, I = decltype(Ic)::value;
     constexpr bool in_lds = J < NL && I > J;
-    f64x4_t acc;
+    V4 acc;
     if (in_lds) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = lt[slot(I, J) * 256 + r * 64];
     } else {
       acc = C[asm_tix(I, J)];
     }
-    const f64x4_t a = K < NL ? P[J] : C[asm_tix(J, K)], b = K < NL ? P[I] : C[asm_tix(I, K)];
+    const V4 a = K < NL ? P[J] : C[asm_tix(J, K)], b = K < NL ? P[I] : C[asm_tix(I, K)];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], acc, 0, 0, 0);
+    for (int s4 = 0; s4 < 4; ++s4) acc = N::mfma(a[s4], b[s4], acc);
     if (in_lds) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) lt[slot(I, J) * 256 + r * 64] = acc[r];
@@ -592,42 +655,42 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
     }
   };
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dt[li * 17 + lq + 4 * r] = -C[asm_tix(0, 0)][r];
+  for (int r = 0; r < 4; ++r) dt[li * 17 + N::kr(lq, r)] = -C[asm_tix(0, 0)][r];
   ASM_FENCE();
 #ifndef DBG_NO_DIAG
-  bad |= asm_diag16(dt, Yt, lane);
+  bad |= asm_diag16<T>(dt, Yt, lane);
 #endif
   ASM_FENCE();
   asm_sfor<0, MB>([&](auto Kc) {
     constexpr int K = decltype(Kc)::value;
     __builtin_amdgcn_sched_barrier(0);
-    double yf[4];                                          // fragments of -Y_K
-    f64x4_t Yc;                                            // Y_K' in C layout: [li][lq + 4r] of Y' = Y[lq + 4r][li]
+    T yf[4];                                               // fragments of -Y_K
+    V4 Yc;                                                 // Y_K' in C layout: [li][kr] of Y' = Y[kr(lq, r)][li]
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) { yf[s4] = -Yt[li * 17 + 4 * s4 + lq]; Yc[s4] = Yt[(lq + 4 * s4) * 17 + li]; }
+    for (int s4 = 0; s4 < 4; ++s4) { yf[s4] = -Yt[li * 17 + N::kr(lq, s4)]; Yc[s4] = Yt[N::kr(lq, s4) * 17 + li]; }
     C[asm_tix(K, K)] = Yc;
     // y_K = Y_K (r_K - sum_{J<K} L(K,J) y_J)
-    const double tK = rv[16 * K + li] - (K ? xsum4(ps[K]) : 0.0);
-    double yq[4];                                          // y_K[lq + 4r]
+    const T tK = rv[16 * K + li] - (K ? xsum4<T>(ps[K]) : T(0));
+    T yq[4];                                               // y_K[kr(lq, r)]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) yq[r] = rowsum16(Yc[r] * tK);
+    for (int r = 0; r < 4; ++r) yq[r] = rowsum16<T>(Yc[r] * tK);
     if (li == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ys[16 * K + lq + 4 * r] = yq[r];
+      for (int r = 0; r < 4; ++r) ys[16 * K + N::kr(lq, r)] = yq[r];
     }
-    f64x4_t P[MB];                                         // the panel of an LDS-resident column (K < NL)
+    V4 P[MB];                                              // the panel of an LDS-resident column (K < NL)
 #pragma unroll
     for (int I = K + 1; I < MB; ++I) {                     // TRSM: L(I,K)' = Y_K S(I,K)'
-      f64x4_t b;
+      V4 b;
       if (K < NL) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) b[r] = lt[slot(I, K) * 256 + r * 64];
       } else {
         b = C[asm_tix(I, K)];
       }
-      f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+      V4 acc = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yf[s4], b[s4], acc, 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) acc = N::mfma(yf[s4], b[s4], acc);
       if (K < NL) {
         P[I] = acc;
 #pragma unroll
@@ -643,7 +706,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
       trail(Kc, asm_ic<K + 1>{}, asm_ic<K + 1>{}, P);      // the next diagonal tile first ...
 #endif
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dt[li * 17 + lq + 4 * r] = -C[asm_tix(K + 1, K + 1)][r];
+      for (int r = 0; r < 4; ++r) dt[li * 17 + N::kr(lq, r)] = -C[asm_tix(K + 1, K + 1)][r];
       ASM_FENCE();
       __builtin_amdgcn_sched_barrier(0);
       // ... then its factorisation together with the rest of the trailing update
@@ -657,50 +720,56 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int bin, int wg)
       });
 #endif
 #ifndef DBG_NO_DIAG
-      bad |= asm_diag16(dt, Yt, lane);
+      bad |= asm_diag16<T>(dt, Yt, lane);
 #endif
       ASM_FENCE();
     }
   });
-  if (bad) { if (lane == 0) d.state[p] = ASM_FALLBACK; return; }
+  if (bad) {
+    // f32: S is not positive definite in this precision -- this round is void (asm_update_k skips the problem,
+    // its LAM row is still zero), the next one runs in fp64.  fp64: hand the problem to the PDIP path.
+    if (lane == 0) { if (N::F32) { d.prec[p] = 1; d.redo[p] = 1; } else d.state[p] = ASM_FALLBACK; }
+    return;
+  }
+  if (!N::F32 && lane == 0) d.prec[p] = 1;                 // solved in fp64 (sets beyond the f32 classes start here)
   ASM_FENCE();
   // ---- backward substitution  L' lam = y
-  double lam[MB];
+  T lam[MB];
 #pragma unroll
   for (int K = MB - 1; K >= 0; --K) {
-    double part = 0.0;
+    T part = T(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      double tt = ys[16 * K + lq + 4 * r];
+      T tt = ys[16 * K + N::kr(lq, r)];
       if (K < MB - 1) {
-        double s4 = 0.0;                                   // (sum_I L(I,K)' lam_I)[lq + 4r], summed over li
+        T s4 = T(0);                                       // (sum_I L(I,K)' lam_I)[kr(lq, r)], summed over li
 #pragma unroll
         for (int I = K + 1; I < MB; ++I) s4 += (K < NL ? lt[slot(I, K) * 256 + r * 64] : C[asm_tix(I, K)][r]) * lam[I];
-        tt -= rowsum16(s4);
+        tt -= rowsum16<T>(s4);
       }
-      part += C[asm_tix(K, K)][r] * tt;                    // Y_K[lq + 4r][li] tt[lq + 4r]
+      part += C[asm_tix(K, K)][r] * tt;                    // Y_K[kr(lq, r)][li] tt[kr(lq, r)]
     }
-    lam[K] = xsum4(part);
+    lam[K] = xsum4<T>(part);
     __builtin_amdgcn_sched_barrier(0);
   }
   double* lrow = d.lam + (size_t)d.row[p] * d.np;
 #pragma unroll
   for (int I = 0; I < MB; ++I) {
     const int i = 16 * I + li;
-    if (lq == 0 && i < m) lrow[idx[i]] = lam[I];
+    if (lq == 0 && i < m) lrow[idx[i]] = (double)lam[I];
   }
 }
 
-// All register-resident size classes in ONE launch (their workgroups are independent; separate
+// All register-resident fp64 size classes 0..5 in ONE launch (their workgroups are independent; separate
 // launches would serialise six tails): workgroup w walks the classes from the largest down and takes
-// four problems of the class its index falls into.  Grid: sum_b ceil(count_b / 4) <= nrun / 4 + ASM_NREG.
-constexpr int ASM_REG_LDS = 4 * asm_rw(ASM_NREG + 3) * 8;  // bytes of dynamic LDS (largest class)
+// four problems of the class its index falls into.  Grid: sum_b ceil(count_b / 4).
+constexpr int ASM_REG_LDS = 4 * asm_rw<double>(ASM_NREG + 3) * 8;  // bytes of dynamic LDS (largest class)
 __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
   int w = blockIdx.x;
 #define ASM_REG_CLASS(B)                                                   \
   {                                                                        \
     const int nb = (d.counters[4 + B] + 3) >> 2;                           \
-    if (w < nb) { asm_lambda_reg<B + 4, 4>(d, B, w); return; }             \
+    if (w < nb) { asm_lambda_reg<double, B + 4, 4>(d, B, w); return; }     \
     w -= nb;                                                               \
   }
   ASM_REG_CLASS(5) ASM_REG_CLASS(4) ASM_REG_CLASS(3) ASM_REG_CLASS(2) ASM_REG_CLASS(1) ASM_REG_CLASS(0)
@@ -708,16 +777,29 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
   static_assert(ASM_NREG == 6, "one ASM_REG_CLASS line per register-resident size class");
 }
 // The 10- and 11-block classes (145..176 bounds): same code, two waves (problems) per workgroup.
-constexpr int ASM_REG2_LDS = 2 * asm_rw(11) * 8;
+constexpr int ASM_REG2_LDS = 2 * asm_rw<double>(11) * 8;
 __global__ __launch_bounds__(128, 1) void asm_lambda_reg2_k(AsmDev d) {
   int w = blockIdx.x;
   {
     const int nb = (d.counters[4 + 7] + 1) >> 1;
-    if (w < nb) { asm_lambda_reg<11, 2>(d, 7, w); return; }
+    if (w < nb) { asm_lambda_reg<double, 11, 2>(d, 7, w); return; }
     w -= nb;
   }
-  asm_lambda_reg<10, 2>(d, 6, w);
+  asm_lambda_reg<double, 10, 2>(d, 6, w);
   static_assert(ASM_NBIN == 8 && ASM_MLDS == 176, "classes 6 and 7 are the 10- and 11-block sets");
+}
+// The f32 rounds of classes 0..5: two workgroups per CU (two waves per SIMD).
+constexpr int ASM_REG32_LDS = 4 * asm_rw<float>(ASM_NREG + 3) * 4;
+__global__ __launch_bounds__(256, 2) void asm_lambda_reg32_k(AsmDev d) {
+  int w = blockIdx.x;
+#define ASM_REG_CLASS(B)                                                            \
+  {                                                                                 \
+    const int nb = (d.counters[ASM_CNT_F32 + B] + 3) >> 2;                          \
+    if (w < nb) { asm_lambda_reg<float, B + 4, 4>(d, ASM_NBIN + B, w); return; }    \
+    w -= nb;                                                                        \
+  }
+  ASM_REG_CLASS(5) ASM_REG_CLASS(4) ASM_REG_CLASS(3) ASM_REG_CLASS(2) ASM_REG_CLASS(1) ASM_REG_CLASS(0)
+#undef ASM_REG_CLASS
 }
 
 // x from the GEMM result, fp64 KKT tests, next active set.  A problem whose set no longer changes
@@ -731,6 +813,11 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= d.nseg || d.state[p] != ASM_RUN) return;
+  if (d.redo[p]) {                                           // the f32 kernel gave up on this set: nothing was computed,
+    if (lane == 0) d.redo[p] = 0;                            // the same set runs again in fp64
+    return;
+  }
+  const bool f32_phase = d.prec[p] == 0;                     // multipliers only good enough to move the set
   const size_t o = (size_t)p * d.np, orow = (size_t)d.row[p] * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
   const int W = min(d.W, d.n);                               // every active bound lies inside the window
@@ -752,7 +839,8 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   }
   for (int off = 32; off > 0; off >>= 1) chg += __shfl_xor(chg, off);
   const int tot = chg;
-  const bool settle_wide = tot == 0 && W < d.n;              // settled inside the window: full-width check next
+  const bool settled = tot == 0 && !f32_phase;               // a set that settles in f32 is solved again in fp64
+  const bool settle_wide = settled && W < d.n;               // settled inside the window: full-width check next
   int wrow = 0;
   if (settle_wide) {
     if (lane == 0) {
@@ -771,7 +859,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
     }
   }
   bool sure = false;
-  if (tot == 0 && !settle_wide) {                            // finished (window = all columns): certificate, and only
+  if (settled && !settle_wide) {                             // finished (window = all columns): certificate, and only
     double x1 = 0.0;                                         // now x is written out, straight into the caller's buffer
     for (int k = lane; k < d.ka; k += 64) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
     for (int off = 32; off > 0; off >>= 1) {
@@ -792,8 +880,9 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   if (lane == 0) {
     const int rd = d.rounds[p] + 1;
     d.rounds[p] = rd;
+    if (tot == 0 && f32_phase) d.prec[p] = 1;
     if (settle_wide) d.state[p] = ASM_WIDE;
-    else if (tot == 0) {
+    else if (settled) {
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
       if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);    // rare: q and x P are formed only for these
     } else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;

@@ -616,6 +616,7 @@ struct nnmpc_qp {
   int* asm_wlist;
   unsigned char* asm_st;
   int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row, *asm_lrank, *asm_ctot;
+  unsigned char *asm_prec, *asm_redo;
   double tqmax;         // max |tq| entry
   int asm_pool;
   double asm_e1max, asm_e2max;
@@ -850,7 +851,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
@@ -896,8 +897,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // workgroup; classes 6, 7 (<= 176) two per workgroup and the rare larger sets (tiles in an L2 slab, one
       // workgroup each: long latency chains on a handful of CUs) beside it on the side stream.
       const int nreg2_wg = (cnt[4 + 6] + 1) / 2 + (cnt[4 + 7] + 1) / 2;
-      int nbig = cnt[1] + nreg2_wg, nreg_wg = 0;
-      for (int b = 0; b < ASM_NREG; ++b) nreg_wg += (cnt[4 + b] + 3) / 4;
+      int nbig = cnt[1] + nreg2_wg, nreg_wg = 0, nreg32_wg = 0;
+      for (int b = 0; b < ASM_NREG; ++b) { nreg_wg += (cnt[4 + b] + 3) / 4; nreg32_wg += (cnt[ASM_CNT_F32 + b] + 3) / 4; }
       if (nbig) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
@@ -905,7 +906,9 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         if (cnt[1]) hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream2, a, 0);
         HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       }
+      // fp64 first (its waves are the long ones), then the f32 rounds of the problems whose set still moves
       if (nreg_wg) hipLaunchKernelGGL(asm_lambda_reg_k, dim3(nreg_wg), dim3(256), ASM_REG_LDS, s, a);
+      if (nreg32_wg) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3(nreg32_wg), dim3(256), ASM_REG32_LDS, s, a);
       if (nbig) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     {
@@ -1036,6 +1039,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
@@ -1081,8 +1085,8 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_lamw, G * np); A_(h->asm_xhw, G * np); A_(h->asm_wlist, G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
-  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NBIN * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_work, 2 * G);
+  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NLIST * G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_work, 2 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }

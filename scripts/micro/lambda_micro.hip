@@ -14,7 +14,7 @@ using namespace nnmpc;
 int main(int argc, char** argv) {
   const int m = argc > 1 ? atoi(argv[1]) : 112;
   const int nseg = argc > 2 ? atoi(argv[2]) : 14336;
-  const int variant = argc > 3 ? atoi(argv[3]) : 0;      // 0 tile kernel, 1 register kernel
+  const int variant = argc > 3 ? atoi(argv[3]) : 0;      // 0 tile kernel, 1 register kernel (fp64), 2 register kernel (f32)
   const int n = 512, np = 512, nu = 32, win = 416, max_active = 768;
   std::mt19937_64 rng(1);
   std::normal_distribution<double> g(0.0, 1.0);
@@ -49,25 +49,29 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dst, st.size())); CK(hipMemcpy(dst, st.data(), st.size(), hipMemcpyHostToDevice));
   CK(hipMalloc(&dstate, nseg * 4)); CK(hipMemset(dstate, 0, nseg * 4));
   int bin = max((m + 15) / 16, 4) - 4; if (bin >= ASM_NBIN) bin = ASM_NBIN - 1;
-  int cnt[16] = {0}; cnt[4 + bin] = nseg;
+  int cnt[ASM_NCNT] = {0}; cnt[4 + bin] = nseg; if (bin < ASM_NREG) cnt[ASM_CNT_F32 + bin] = nseg;
   CK(hipMalloc(&dcnt, sizeof cnt)); CK(hipMemcpy(dcnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
-  CK(hipMalloc(&dbin, (size_t)ASM_NBIN * nseg * 4));
-  for (int b = 0; b < ASM_NBIN; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dbin, (size_t)ASM_NLIST * nseg * 4));
+  for (int b = 0; b < ASM_NLIST; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&didx, idx.size() * 4)); CK(hipMemcpy(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&dmg, nseg * 4)); CK(hipMemcpy(dmg, mg.data(), nseg * 4, hipMemcpyHostToDevice));
   d.H = dH; d.lb = dlb; d.ub = dub; d.xunc = dxu; d.lam = dlam; d.st = dst; d.state = dstate; d.counters = dcnt;
   d.binlist = dbin; d.idxg = didx; d.mg = dmg;
+  unsigned char *dprec, *dredo; CK(hipMalloc(&dprec, nseg)); CK(hipMemset(dprec, 0, nseg)); CK(hipMalloc(&dredo, nseg)); CK(hipMemset(dredo, 0, nseg));
+  d.prec = dprec; d.redo = dredo;
   int* drow; CK(hipMalloc(&drow, nseg * 4)); CK(hipMemcpy(drow, list.data(), nseg * 4, hipMemcpyHostToDevice)); d.row = drow;
   const int mbc = asm_bin_cap(bin) / 16;
   const int lds_tile = (asm_bin_cap(bin) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
   CK(hipFuncSetAttribute((const void*)asm_lambda_tile_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (ASM_MLDS + ASM_TS + 66 * ASM_TS) * 8));
   CK(hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS));
   CK(hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS));
+  CK(hipFuncSetAttribute((const void*)asm_lambda_reg32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32_LDS));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
     if (variant == 0) hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nseg), dim3(256), lds_tile, 0, d, bin);
+    else if (variant == 2) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG32_LDS, 0, d);
     else {
       if (bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, 0, d);
       else hipLaunchKernelGGL(asm_lambda_reg2_k, dim3((nseg + 1) / 2 + 2), dim3(128), ASM_REG2_LDS, 0, d);
