@@ -34,8 +34,9 @@ def _qp(P, nu, **kw):
     return BatchedBoxQP(P, np.eye(n), nu, method="asm", max_batch=128, **kw)   # tq = I: q = x0
 
 
+@pytest.mark.parametrize("f32_rounds", [0, -1])       # 0: rounds in f32 until the set settles, then fp64; -1: fp64 throughout
 @pytest.mark.parametrize("n_active_target", [20, 60, 72, 85, 98, 110, 122, 135, 145, 230])
-def test_size_classes(n_active_target):
+def test_size_classes(n_active_target, f32_rounds):
     """Sets of ~20 .. ~280 bounds (the couplings add ~20 % to the pushed ones): every kernel variant must
     reproduce the exact optimum and set."""
     n, nu, B = 512, 8, 12
@@ -46,7 +47,7 @@ def test_size_classes(n_active_target):
     q = 0.05 * rng.standard_normal((B, n))
     push = rng.choice([-1.0, 1.0], (B, n_active_target)) * rng.uniform(30.0, 60.0, (B, n_active_target))
     q[:, :n_active_target] += push * np.diag(P)[:n_active_target]
-    qp = _qp(P, nu)
+    qp = _qp(P, nu, asm_f32_rounds=f32_rounds)
     out = qp.solve_batch(q, lb, ub)
     st = qp.stats()
     assert (out["status"] == 0).all(), out["status"]
