@@ -888,9 +888,9 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     kprev = cnt[3];
     if (nrun == 0) break;
     h->stats.asm_rounds += 1;
-    // column window of this round: past the last active bound of any running problem plus four stages; a
+    // column window of this round: past the last active bound of any running problem plus one stage; a
     // problem that settles inside it gets one full-width pass (asm_wide_k) at the start of the next round
-    a.W = std::min(h->np, ((cnt[3] + 1 + 4 * h->nu + 127) / 128) * 128);
+    a.W = std::min(h->np, ((cnt[3] + 1 + h->nu + 127) / 128) * 128);
     {
       EvScope es(h, 4, 0.0);
       // one wave per problem, S in registers: size classes 0..5 (<= 144 bounds) in one launch, four problems per
