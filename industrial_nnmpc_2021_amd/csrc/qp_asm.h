@@ -29,12 +29,12 @@ enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4 }
 constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
 constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds): four problems per workgroup (asm_lambda_reg_k); 6, 7: two
 constexpr int ASM_NCNT = 24;       // ints in AsmDev::counters
-constexpr int ASM_CNT_F32 = 16;    // counters[16 + b]: length of the f32 list of size class b < ASM_NREG
-constexpr int ASM_NLIST = ASM_NBIN + ASM_NREG;   // lists in AsmDev::binlist: fp64 classes, then f32 classes
+constexpr int ASM_CNT_F32 = 16;    // counters[16 + b]: length of the f32 list of size class b
+constexpr int ASM_NLIST = 2 * ASM_NBIN;   // lists in AsmDev::binlist: fp64 classes, then f32 classes
 constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check ([13]: handled by the last asm_wide_k)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
-// ASM_NBIN + b (b < ASM_NREG) the f32 ones (counters[ASM_CNT_F32 + b])
+// ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
 __host__ __device__ constexpr int asm_list_counter(int list) { return list < ASM_NBIN ? 4 + list : ASM_CNT_F32 + list - ASM_NBIN; }
 constexpr int ASM_NSCAN = ASM_NLIST + 3;  // scan columns: running, large sets, the lists, max active index
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
@@ -182,7 +182,7 @@ __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {
   const int m = d.mg[p];
   if (m > ASM_MLDS) return 0;
   const int b = max((m + 15) / 16, 4) - 4;
-  return 1 + ((d.prec[p] == 0 && b < ASM_NREG) ? ASM_NBIN + b : b);
+  return 1 + (d.prec[p] == 0 ? ASM_NBIN + b : b);
 }
 __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   __shared__ int wtot[ASM_NSCAN][16];
@@ -516,7 +516,7 @@ template <class T> __device__ __forceinline__ T xsum4(T x) { return AsmNum<T>::s
 
 // tiles of the first NL block columns kept in LDS; LDS elements per wave
 template <class T> __host__ __device__ constexpr int asm_nl(int mb) {
-  return AsmNum<T>::F32 ? (mb <= 7 ? 0 : 2) : (mb <= 7 ? 0 : (mb <= 9 ? 2 : 4));
+  return mb <= 7 ? 0 : (mb <= 9 ? 2 : 4);
 }
 template <class T> __host__ __device__ constexpr int asm_nlt(int mb) { return asm_nl<T>(mb) * (mb - 1) - asm_nl<T>(mb) * (asm_nl<T>(mb) - 1) / 2; }
 template <class T> __host__ __device__ constexpr int asm_rw(int mb) { return 2 * ASM_TS + 2 * mb * 16 + asm_nlt<T>(mb) * 256; }
@@ -802,6 +802,18 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_reg32_k(AsmDev d) {
 #undef ASM_REG_CLASS
 }
 
+// ... and of classes 6, 7: four waves per workgroup, one workgroup per CU (LDS).
+constexpr int ASM_REG32B_LDS = 4 * asm_rw<float>(11) * 4;
+__global__ __launch_bounds__(256, 1) void asm_lambda_reg32b_k(AsmDev d) {
+  int w = blockIdx.x;
+  {
+    const int nb = (d.counters[ASM_CNT_F32 + 7] + 3) >> 2;
+    if (w < nb) { asm_lambda_reg<float, 11, 4>(d, ASM_NBIN + 7, w); return; }
+    w -= nb;
+  }
+  asm_lambda_reg<float, 10, 4>(d, ASM_NBIN + 6, w);
+}
+
 // x from the GEMM result, fp64 KKT tests, next active set.  A problem whose set no longer changes
 // is certified right here when the verified inverse allows it:  with E1 = P Kunc + tq and
 // E2 = P Pinv - I (maxima e1max, e2max computed once at setup),
@@ -992,18 +1004,26 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
   const double gfm = fmax(fmax(gq[0], gq[1]), fmax(gq[2], gq[3]));
   const int ok = nbad == 0 && gfm <= d.stat_tol * fmax(gscale_min, qs);
   if (d.act_out) {
-    const int m2 = 2 * d.n;
-    for (int w = tid; w < d.words; w += 256) {
-      uint32_t bits = 0;
-      for (int b = 0; b < 32; ++b) {
-        const int i = 32 * w + b;
-        if (i < m2) {
-          const int kk = i / (2 * d.nu), c = i % (2 * d.nu);
-          const int hit = (c < d.nu) ? (st[kk * d.nu + c] == 1) : (st[kk * d.nu + c - d.nu] == 2);
-          bits |= (uint32_t)hit << b;
+    // bit k*2nu + c: upper bound of variable k*nu + c active, bit k*2nu + nu + c: lower bound (row order of the
+    // reference's G).  One pass over the bound states (one division per variable), words assembled in LDS.
+    __shared__ uint32_t wb[1024];
+    for (int w0 = 0; w0 < d.words; w0 += 1024) {
+      const int nwd = min(1024, d.words - w0);
+      for (int w = tid; w < nwd; w += 256) wb[w] = 0u;
+      __syncthreads();
+      // variables whose two bits fall into words [w0, w0 + nwd): stages [32 w0 / 2nu, 32 (w0 + nwd) / 2nu]
+      const int k0 = (32 * w0) / (2 * d.nu), k1 = min(d.n / d.nu, (32 * (w0 + nwd) + 2 * d.nu - 1) / (2 * d.nu));
+      for (int r = k0 * d.nu + tid; r < k1 * d.nu; r += 256) {
+        const int sv = st[r];
+        if (sv) {
+          const int kk = r / d.nu, c = r - kk * d.nu;
+          const int bit = kk * 2 * d.nu + (sv == 1 ? c : d.nu + c), w = (bit >> 5) - w0;
+          if (w >= 0 && w < nwd) atomicOr(&wb[w], 1u << (bit & 31));
         }
       }
-      d.act_out[(size_t)p * d.words + w] = bits;
+      __syncthreads();
+      for (int w = tid; w < nwd; w += 256) d.act_out[(size_t)p * d.words + w0 + w] = wb[w];
+      __syncthreads();
     }
   }
   if (tid == 0) {

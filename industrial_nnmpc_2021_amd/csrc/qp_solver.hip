@@ -897,12 +897,14 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // workgroup; classes 6, 7 (<= 176) two per workgroup and the rare larger sets (tiles in an L2 slab, one
       // workgroup each: long latency chains on a handful of CUs) beside it on the side stream.
       const int nreg2_wg = (cnt[4 + 6] + 1) / 2 + (cnt[4 + 7] + 1) / 2;
-      int nbig = cnt[1] + nreg2_wg, nreg_wg = 0, nreg32_wg = 0;
+      const int nreg32b_wg = (cnt[ASM_CNT_F32 + 6] + 3) / 4 + (cnt[ASM_CNT_F32 + 7] + 3) / 4;
+      int nbig = cnt[1] + nreg2_wg + nreg32b_wg, nreg_wg = 0, nreg32_wg = 0;
       for (int b = 0; b < ASM_NREG; ++b) { nreg_wg += (cnt[4 + b] + 3) / 4; nreg32_wg += (cnt[ASM_CNT_F32 + b] + 3) / 4; }
       if (nbig) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         if (nreg2_wg) hipLaunchKernelGGL(asm_lambda_reg2_k, dim3(nreg2_wg), dim3(128), ASM_REG2_LDS, h->stream2, a);
+        if (nreg32b_wg) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3(nreg32b_wg), dim3(256), ASM_REG32B_LDS, h->stream2, a);
         if (cnt[1]) hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream2, a, 0);
         HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       }
@@ -1040,6 +1042,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32b_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32B_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
