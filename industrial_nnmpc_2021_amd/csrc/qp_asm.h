@@ -911,6 +911,10 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
   if (w >= d.counters[ASM_CNT_WIDE]) return;
   const int p = d.wlist[w];
   const size_t o = (size_t)p * d.np, orow = (size_t)w * d.np;
+  // columns inside the window the problem settled in (d.W is still that round's) were evaluated by that round's
+  // GEMM: its row of XH is untouched until this round's GEMM; only the columns beyond come from XHW
+  const size_t onar = (size_t)d.row[p] * d.np;
+  const int Wp = min(d.W, d.n);
   unsigned char* st = d.st + (size_t)p * d.n;
   int chg = 0;
   double l1 = 0.0, lmin = 1e300;
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
     const int s = st[r];
     double x;
     if (s == 0) {
-      x = d.xunc[o + r] - d.xhw[orow + r];
+      x = d.xunc[o + r] - (r < Wp ? d.xh[onar + r] : d.xhw[orow + r]);
       if (x > ub + d.bound_tol) { st[r] = 1; ++chg; }
       else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
     } else {

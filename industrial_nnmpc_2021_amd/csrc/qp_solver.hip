@@ -868,8 +868,10 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // problems that settled inside last round's column window: all columns of x, once
       {
         EvScope es(h, 5, 0.0);
-        gemm64(h, h->asm_xhw, h->np, h->asm_lamw, h->np, h->H64, h->np, ((prev_run + 127) / 128) * 128, h->np, h->np, nullptr, 0,
-               h->asm_counters + 3, h->asm_counters + ASM_CNT_WIDE);
+        // (a.W is still last round's window: those columns are in that round's XH rows already)
+        const int c0 = (a.W < h->np && (h->np - a.W) % 128 == 0) ? a.W : 0;
+        gemm64(h, h->asm_xhw + c0, h->np, h->asm_lamw, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_run + 127) / 128) * 128,
+               h->np - c0, h->np, nullptr, 0, h->asm_counters + 3, h->asm_counters + ASM_CNT_WIDE);
       }
       EvScope es(h, 6, 0.0);
       hipLaunchKernelGGL(asm_wide_k, dim3(prev_run), dim3(256), 0, s, a);
