@@ -92,7 +92,7 @@ struct AsmDev {
 
 __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }
 
-// x_unc -> first active-set estimate: every bound the unconstrained minimiser violates.
+// x_unc -> first active-set estimate.
 __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
   const int p = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)p * d.np;
@@ -100,12 +100,18 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     if (tid == 0) d.state[p] = ASM_DONE;
     return;
   }
+  // first set: the bounds x_unc violates in the leading quarter of the horizon (where MPC saturates; a violation
+  // further out is found by the full-width pass every problem goes through before it is accepted), or the guess
+  const int wi = d.guess ? d.n : min(d.n, max(512, ((d.n / 4 + 127) / 128) * 128));
   for (int r = tid; r < d.n; r += 256) {
-    const int k = r % d.nu;
-    const double x = d.xunc[o + r];
-    const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
-    int s = x > ub ? 1 : (x < lb ? 2 : 0);
+    int s = 0;
     if (d.guess) { s = d.guess[(size_t)p * d.n + r]; if (s > 2) s = 0; }
+    else if (r < wi) {
+      const int k = r % d.nu;
+      const double x = d.xunc[o + r];
+      const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
+      s = x > ub ? 1 : (x < lb ? 2 : 0);
+    }
     d.st[(size_t)p * d.n + r] = (unsigned char)s;
   }
   // an empty set runs one round like the others: x = x_unc is checked and certified by asm_update_k / asm_wide_k
@@ -833,21 +839,23 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   const size_t o = (size_t)p * d.np, orow = (size_t)d.row[p] * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
   const int W = min(d.W, d.n);                               // every active bound lies inside the window
+  const int m = d.mg[p];                                     // this round's set: idx[0..m) (asm_count_k)
+  const int* idx = d.idxg + (size_t)p * d.max_active;
   int chg = 0;
   double l1 = 0.0, lmin = 1e300;
-  for (int r = lane; r < W; r += 64) {
+  for (int r = lane; r < W; r += 64) {                       // free variables of the window: feasibility
+    if (st[r]) continue;
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
-    const int s = st[r];
-    if (s == 0) {
-      const double x = d.xunc[o + r] - d.xh[orow + r];
-      if (x > ub + d.bound_tol) { st[r] = 1; ++chg; }
-      else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
-    } else {
-      const double l = d.lam[orow + r];
-      l1 += fabs(l); lmin = fmin(lmin, fabs(l));
-      if ((s == 1 && l <= 0.0) || (s == 2 && l >= 0.0)) { st[r] = 0; ++chg; }   // keep iff multiplier > 0
-    }
+    const double x = d.xunc[o + r] - d.xh[orow + r];
+    if (x > ub + d.bound_tol) { st[r] = 1; ++chg; }
+    else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
+  }
+  for (int i = lane; i < m; i += 64) {                       // active bounds: multiplier signs
+    const int a = idx[i], sa = st[a];
+    const double l = d.lam[orow + a];
+    l1 += fabs(l); lmin = fmin(lmin, fabs(l));
+    if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { st[a] = 0; ++chg; }   // keep iff multiplier > 0
   }
   for (int off = 32; off > 0; off >>= 1) chg += __shfl_xor(chg, off);
   const int tot = chg;
@@ -865,9 +873,11 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   // multipliers along into its row of LAMW
   {
     double* lw = settle_wide ? d.lamw + (size_t)wrow * d.np : nullptr;
-    for (int r = lane; r < W; r += 64) {
-      const double l = d.lam[orow + r];
-      if (l != 0.0) { d.lam[orow + r] = 0.0; if (lw) lw[r] = l; }
+    for (int i = lane; i < m; i += 64) {
+      const int a = idx[i];
+      const double l = d.lam[orow + a];
+      d.lam[orow + a] = 0.0;
+      if (lw) lw[a] = l;
     }
   }
   bool sure = false;
