@@ -31,6 +31,7 @@ constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds): four problem
 constexpr int ASM_NCNT = 24;       // ints in AsmDev::counters
 constexpr int ASM_CNT_F32 = 16;    // counters[16 + b]: length of the f32 list of size class b
 constexpr int ASM_NLIST = 2 * ASM_NBIN;   // lists in AsmDev::binlist: fp64 classes, then f32 classes
+constexpr int ASM_GRACE = 10;       // rounds without a new minimum of infeasible indices before single exchanges take over
 constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check ([13]: handled by the last asm_wide_k)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
@@ -70,6 +71,8 @@ struct AsmDev {
                                    // 0..nrun-1 (counters[2]), so the GEMM only covers those
   double tqmax;                    // max |tq| entry: |q|_inf <= tqmax |x0|_1 (q itself is only formed for the full check)
   unsigned char* prec;             // [nseg] 0: rounds in f32 until the set settles, 1: fp64 (only these results are accepted)
+  int* ninf_best;                  // [nseg] smallest number of infeasible indices seen so far (exchange rule of asm_update_k)
+  unsigned char* alpha;            // [nseg] rounds of grace left before single exchanges
   unsigned char* redo;             // [nseg] set by the f32 kernel when S is not positive definite in f32: the round is void
   int* lrank;                      // [nseg] asm_bins scratch: rank inside its chunk and list
   int* ctot;                       // [chunks][ASM_NSCAN] asm_bins scratch: per-chunk totals, last column: max active index
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     d.rounds[p] = 0; d.state[p] = ASM_RUN;
     d.prec[p] = (d.use_f32 && !d.guess) ? 0 : 1;       // a caller's guess is expected to be right: confirm it in fp64 at once
     d.redo[p] = 0;
+    d.ninf_best[p] = 0x7fffffff; d.alpha[p] = ASM_GRACE;
   }
 }
 
@@ -841,24 +845,59 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   const int W = min(d.W, d.n);                               // every active bound lies inside the window
   const int m = d.mg[p];                                     // this round's set: idx[0..m) (asm_count_k)
   const int* idx = d.idxg + (size_t)p * d.max_active;
-  int chg = 0;
+  // Exchange rule (block principal pivoting with Murty's fallback: Judice & Pires 1994, Kim & Park 2011): all
+  // infeasible indices change sides as long as their number keeps falling -- with ASM_GRACE rounds of grace --,
+  // otherwise only the infeasible variable with the largest index does.  The plain all-at-once rule cycles on
+  // ill-conditioned Hessians (6 of 131 072 samples of the cond-4e7 CSTRs-size plant); the fallback is finite.
+  __shared__ unsigned short ch_r[4][8][64];                  // this lane's first changes: index, new state
+  __shared__ unsigned char ch_s[4][8][64];
+  const int wv = threadIdx.x >> 6;
+  int chg = 0, rmax = -1;
   double l1 = 0.0, lmin = 1e300;
-  for (int r = lane; r < W; r += 64) {                       // free variables of the window: feasibility
-    if (st[r]) continue;
-    const int k = r % d.nu;
-    const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
-    const double x = d.xunc[o + r] - d.xh[orow + r];
-    if (x > ub + d.bound_tol) { st[r] = 1; ++chg; }
-    else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
-  }
-  for (int i = lane; i < m; i += 64) {                       // active bounds: multiplier signs
-    const int a = idx[i], sa = st[a];
-    const double l = d.lam[orow + a];
-    l1 += fabs(l); lmin = fmin(lmin, fabs(l));
-    if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { st[a] = 0; ++chg; }   // keep iff multiplier > 0
-  }
-  for (int off = 32; off > 0; off >>= 1) chg += __shfl_xor(chg, off);
+  auto scan = [&](int mode) {                                // 0: count and record, 1: apply all, 2: apply only index rmax
+    for (int r = lane; r < W; r += 64) {                     // free variables of the window: feasibility
+      if (st[r]) continue;
+      const int k = r % d.nu;
+      const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
+      const double x = d.xunc[o + r] - d.xh[orow + r];
+      const int ns = x > ub + d.bound_tol ? 1 : (x < lb - d.bound_tol ? 2 : 0);
+      if (!ns) continue;
+      if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)r; ch_s[wv][chg][lane] = (unsigned char)ns; } ++chg; rmax = max(rmax, r); }
+      else if (mode == 1 || r == rmax) st[r] = (unsigned char)ns;
+    }
+    for (int i = lane; i < m; i += 64) {                     // active bounds: multiplier signs (keep iff multiplier > 0)
+      const int a = idx[i], sa = st[a];
+      const double l = d.lam[orow + a];
+      if (mode == 0) { l1 += fabs(l); lmin = fmin(lmin, fabs(l)); }
+      if (!((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0))) continue;
+      if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)a; ch_s[wv][chg][lane] = 0; } ++chg; rmax = max(rmax, a); }
+      else if (mode == 1 || a == rmax) st[a] = 0;
+    }
+  };
+  scan(0);
+  const int mych = chg;
+  const bool overflow = __any(mych > 8) || d.n > 65535;
+  for (int off = 32; off > 0; off >>= 1) { chg += __shfl_xor(chg, off); rmax = max(rmax, __shfl_xor(rmax, off)); }
   const int tot = chg;
+  if (tot > 0) {
+    int single = 0;
+    if (lane == 0) {
+      const int best = d.ninf_best[p];
+      int alpha = d.alpha[p];
+      if (tot < best) { d.ninf_best[p] = tot; alpha = ASM_GRACE; }
+      else if (alpha > 0) --alpha;
+      else { single = 1; d.prec[p] = 1; }                    // the careful rule works on fp64 multipliers only
+      d.alpha[p] = (unsigned char)alpha;
+    }
+    single = __shfl(single, 0);
+    if (overflow) scan(single ? 2 : 1);                      // rare (window = all columns): decide again, with the writes
+    else {
+      for (int i = 0; i < mych; ++i) {
+        const int r = ch_r[wv][i][lane];
+        if (!single || r == rmax) st[r] = ch_s[wv][i][lane];
+      }
+    }
+  }
   const bool settled = tot == 0 && !f32_phase;               // a set that settles in f32 is solved again in fp64
   const bool settle_wide = settled && W < d.n;               // settled inside the window: full-width check next
   int wrow = 0;
@@ -970,7 +1009,10 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
     if (tot == 0) {
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
       if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);    // rare: q and x P are formed only for these
-    } else d.state[p] = d.rounds[p] >= d.max_rounds ? ASM_FALLBACK : ASM_RUN;
+    } else {
+      d.state[p] = d.rounds[p] >= d.max_rounds ? ASM_FALLBACK : ASM_RUN;
+      d.ninf_best[p] = 0x7fffffff; d.alpha[p] = ASM_GRACE;          // new bounds joined: the exchange rule starts afresh
+    }
   }
 }
 

@@ -136,3 +136,29 @@ def test_full_check_with_P_when_inverse_is_only_approximate():
         assert (out["active"][b] == act).all()
         nact += int(act.sum())
     assert nact > B
+
+
+def test_cycling_samples_of_the_ill_conditioned_plant():
+    """Six samples of the cond-4e7 CSTRs-size plant on which the all-at-once exchange rule cycles for ever (and the
+    PDIP path's polish with it): the single-exchange fallback of asm_update_k must bring them to the optimum."""
+    from industrial_nnmpc_2021_amd import synthetic
+    from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    pl = synthetic.plant("cstrs", 0)
+    P, tq, nu = build_regulator_matrices(pl)
+    n = P.shape[0]
+    s = synthetic.samples(pl, 131072, 1, 2.0)
+    rows = np.array([836, 5564, 7016, 14320, 63988, 126862])
+    x0 = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), 1)[rows]
+    lb, ub = (pl["ulb"].T - s["us"])[rows], (pl["uub"].T - s["us"])[rows]
+    qp = BatchedBoxQP(P, tq, nu, nb=64, max_batch=128, method="asm")
+    out = qp.solve_batch(x0, lb, ub)
+    assert (out["status"] == 0).all(), out["status"]
+    assert qp.stats()["asm_rounds"] > 12           # they do need the fallback
+    Ps = np.tril(P) + np.tril(P, -1).T
+    for b in range(len(rows)):
+        info = {"nu": nu}
+        xe = oqp.solve_exact_box(Ps, tq @ x0[b], np.tile(lb[b], n // nu), np.tile(ub[b], n // nu), info=info)
+        act = np.zeros(2 * n, bool); act[info["active"]] = True
+        assert np.abs(out["u"][b] - xe).max() / max(1.0, np.abs(xe).max()) <= 1e-6, b
+        assert (out["active"][b] == act).all(), b
