@@ -57,9 +57,9 @@ typedef struct {
   int32_t max_batch;         /* resident problems per wave (rounded up to 128); 0 = 1024 */
   int32_t nb;                /* Cholesky block 64 | 128; 0 = auto */
   int32_t max_ipm_iters;     /* 0 = 40 */
-  int32_t max_polish_rounds; /* 0 = 40 */
+  int32_t max_polish_rounds; /* 0 = 150 (the single-exchange fallback against cycling may take one round per bound) */
   int32_t max_refine;        /* PCG steps per active set; 0 = 60 */
-  int32_t max_rounds;        /* lock-step rounds a problem may stay resident; 0 = 250 */
+  int32_t max_rounds;        /* lock-step rounds a problem may stay resident; 0 = 1000 */
   int32_t sub_steps;         /* solve sub-steps (PCG steps / KKT check) per round; 0 = 8 */
   int32_t stale_max_changes; /* polish: reuse the previous factor as PCG preconditioner when at most
                                 this many bounds changed; 0 = 4, < 0 = always refactor */

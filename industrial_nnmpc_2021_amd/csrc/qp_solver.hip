@@ -38,6 +38,7 @@ enum { PH_INIT = 0, PH_IPM = 1, PH_POLISH = 2, PH_DONE = 3 };
 enum { PS_START = 0, PS_CG = 1, PS_CHECK = 2 };
 enum { CNT_ACTIVE = 0, CNT_FACTOR = 1, CNT_IPM = 2, CNT_POLISH = 3, CNT_SOLVE = 4 };
 
+constexpr int POLISH_GRACE = 10;   // polish rounds without a new minimum of infeasible indices before single exchanges
 struct QpDev {
   int n, np, nu, slots;
   int max_ipm, max_polish, max_refine, stale_max_changes, stale_cg_limit;
@@ -57,6 +58,7 @@ struct QpDev {
   int *slot_prob, *age, *next_prob;
   int seg_count, max_rounds;
   int *phase, *f_factor, *f_solve, *istep, *ipm_it, *nfac, *prounds, *rcnt, *psub, *fail, *stale;
+  int *pninf, *pgrace;   // polish exchange rule: fewest infeasible indices seen, rounds of grace left (see kkt_check)
   float *mu, *gap, *smu, *qscale;
   double* rz;
   int* counters;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) void refill_k(QpDev d) {
     d.phase[p] = warm ? PH_POLISH : PH_INIT;
     d.f_factor[p] = d.f_solve[p] = 0;
     d.ipm_it[p] = d.nfac[p] = d.prounds[p] = d.rcnt[p] = d.psub[p] = d.fail[p] = d.stale[p] = 0;
+    d.pninf[p] = 0x7fffffff; d.pgrace[p] = POLISH_GRACE;
     d.mu[p] = d.gap[p] = d.smu[p] = 0.f; d.rz[p] = 0.0;
   }
 }
@@ -317,12 +320,36 @@ __device__ int kkt_check(const QpDev& d, int p, int* shi, double* shd) {
     if (tid == 0) { d.phase[p] = PH_DONE; d.f_factor[p] = d.f_solve[p] = 0; }
     return 1;
   }
+  // Exchange rule (block principal pivoting with single-exchange fallback, as in asm_update_k): every infeasible
+  // index changes sides while their number keeps reaching new minima (POLISH_GRACE rounds of grace), after that only
+  // the one with the largest index -- the all-at-once rule can cycle for ever on ill-conditioned Hessians.
+  int single = 0, rsel = -1;
+  {
+    const int best = d.pninf[p], grace = d.pgrace[p];
+    __syncthreads();
+    if (bad < best) { if (tid == 0) { d.pninf[p] = bad; d.pgrace[p] = POLISH_GRACE; } }
+    else if (grace > 0) { if (tid == 0) d.pgrace[p] = grace - 1; }
+    else single = 1;
+  }
+  if (single) {
+    double rm = -1.0;
+    for (int r = tid; r < n; r += 256) {
+      const int c = r % d.nu;
+      const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
+      const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
+      const int s = d.st[o + r];
+      const bool inf = s == 0 ? ((x > ub + d.bound_tol) || (x < lb - d.bound_tol)) : (s == 1 ? g >= 0.0 : g <= 0.0);
+      if (inf) rm = (double)r;
+    }
+    rsel = (int)block_maxd(rm, shd);
+  }
   for (int r = tid; r < n; r += 256) {
     const int c = r % d.nu;
     const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
     const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
     const int s = d.st[o + r];
     double xn = x;
+    if (single && r != rsel) { d.v64[o + r] = xn; continue; }
     if (s == 0) {
       if (x > ub + d.bound_tol) { d.st[o + r] = 1; xn = ub; }
       else if (x < lb - d.bound_tol) { d.st[o + r] = 2; xn = lb; }
@@ -1010,9 +1037,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.nb == 0) o.nb = (n <= 1024) ? 64 : 128;
   if (o.nb != 64 && o.nb != 128) { set_error("nb must be 64 or 128"); delete h; return NNMPC_EINVAL; }
   if (o.max_ipm_iters <= 0) o.max_ipm_iters = 40;
-  if (o.max_polish_rounds <= 0) o.max_polish_rounds = 40;
+  if (o.max_polish_rounds <= 0) o.max_polish_rounds = 150;
   if (o.max_refine <= 0) o.max_refine = 60;
-  if (o.max_rounds <= 0) o.max_rounds = 250;
+  if (o.max_rounds <= 0) o.max_rounds = 1000;
   if (o.sub_steps <= 0) o.sub_steps = 8;
   if (o.stale_max_changes == 0) o.stale_max_changes = 4;   // < 0 disables factor reuse
   if (o.stale_cg_limit <= 0) o.stale_cg_limit = 16;
@@ -1066,7 +1093,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.rd, V); A_(d.rhs, V); A_(d.sol, V); A_(d.dua, V); A_(d.dvec, V); A_(d.mask, V); A_(d.uunc, V);
   A_(d.x, V); A_(d.q64, V); A_(d.PX, V); A_(d.r64, V); A_(d.p64, V); A_(d.v64, V); A_(d.st, V);
   A_(d.phase, S); A_(d.f_factor, S); A_(d.f_solve, S); A_(d.istep, S); A_(d.ipm_it, S);
-  A_(d.nfac, S); A_(d.prounds, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.stale, S); A_(d.rz, S);
+  A_(d.nfac, S); A_(d.prounds, S); A_(d.pninf, S); A_(d.pgrace, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.stale, S); A_(d.rz, S);
   A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
   {
     // segment size: as many problems as a quarter of the free HBM allows (per problem: q f64, warm start f32 and the
