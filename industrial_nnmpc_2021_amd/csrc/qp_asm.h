@@ -8,15 +8,20 @@
 //      lam = (H_AA)^-1 (x_unc,A - b_A),     x = x_unc - H[:,A] lam,     x_unc = -H q = Kunc x0,
 // (lam = multipliers: > 0 at an upper bound, < 0 at a lower bound when the set is right).
 // A primal-dual active-set iteration (add violated bounds, drop wrong-sign multipliers)
-// therefore costs  |A|^3/3 + O(|A|^2)  per problem (dense fp64 Cholesky of the |A| x |A|
-// block of H, in LDS) plus one row of the batched fp64 GEMM  LAM * H  -- no n^3 work at all.
+// therefore costs  |A|^3/3 + O(|A|^2)  per problem (dense Cholesky of the |A| x |A| block of H, held in
+// the MFMA accumulators of one wave) plus one row of the batched fp64 GEMM  LAM * H  -- no n^3 work at all.
 // Problems whose set is too large, or that do not settle, fall back to the PDIP path.
 //
-// Per round (all unfinished problems of a segment in lock-step, 3 launches):
-//   asm_lambda_k : compact A, gather S = H_AA, Cholesky, lam -> dense row of LAM
-//   gemm_nt_f64  : XH = LAM * H                                   (MFMA f64)
-//   asm_update_k : x = x_unc - XH (free), x = bound (active); fp64 KKT sign / feasibility
-//                  tests -> new set, or finished
+// Per round (all unfinished problems of a segment in lock-step; the host reads 24 counters once):
+//   asm_wide_k            full-width check of the problems that settled inside last round's column window
+//   asm_count_k           ordered list of the active indices of every running problem
+//   asm_bins_a/b_k        scans: row of LAM / XH for this round (running problems packed), size-class lists
+//   asm_lambda_reg*_k     gather S = H_AA, Cholesky, lam -> row of LAM   (f32 until the set settles, then fp64)
+//   gemm_nt_f64_128_k     XH = LAM * H inside the column window          (MFMA f64)
+//   asm_update_k          x = x_unc - XH (free), x = bound (active); fp64 feasibility / multiplier-sign tests ->
+//                         next set (exchange rule with anti-cycling fallback), or settled -> full-width pass
+// and once per segment asm_init_k (first sets) and asm_certify_k (active-set bits, status, check with P itself
+// for the rows the inverse-error bound cannot certify).  DESIGN.md section 2a has the details.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -624,11 +629,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
 #pragma unroll
         for (int I = J; I < MB; ++I) {                     // unconditional (clamped) loads, then select
           const int gi = 16 * I + li;
-#ifdef DBG_NO_GATHER
-          const double v = 0.001 * (double)(gcol[I] & 7);
-#else
           const double v = Hr[gcol[I]];
-#endif
           const T e = (gi < m && gj < m) ? (T)(-v) : (gi == gj ? T(-1) : T(0));
           if (J < NL && I > J) lt[slot(I, J) * 256 + r * 64] = e;
           else C[asm_tix(I, J)][r] = e;
@@ -667,9 +668,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
 #pragma unroll
   for (int r = 0; r < 4; ++r) dt[li * 17 + N::kr(lq, r)] = -C[asm_tix(0, 0)][r];
   ASM_FENCE();
-#ifndef DBG_NO_DIAG
   bad |= asm_diag16<T>(dt, Yt, lane);
-#endif
   ASM_FENCE();
   asm_sfor<0, MB>([&](auto Kc) {
     constexpr int K = decltype(Kc)::value;
@@ -712,15 +711,12 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
       for (int r = 0; r < 4; ++r) ps[I] += acc[r] * yq[r];
     }
     if constexpr (K + 1 < MB) {
-#ifndef DBG_NO_TRAIL
       trail(Kc, asm_ic<K + 1>{}, asm_ic<K + 1>{}, P);      // the next diagonal tile first ...
-#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) dt[li * 17 + N::kr(lq, r)] = -C[asm_tix(K + 1, K + 1)][r];
       ASM_FENCE();
       __builtin_amdgcn_sched_barrier(0);
       // ... then its factorisation together with the rest of the trailing update
-#ifndef DBG_NO_TRAIL
       asm_sfor<K + 1, MB>([&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
         asm_sfor<J, MB>([&](auto Ic) {
@@ -728,10 +724,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
           if constexpr (!(I == K + 1 && J == K + 1)) trail(Kc, Jc, Ic, P);
         });
       });
-#endif
-#ifndef DBG_NO_DIAG
       bad |= asm_diag16<T>(dt, Yt, lane);
-#endif
       ASM_FENCE();
     }
   });
