@@ -38,6 +38,36 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_k(float* __restrict__ C, size
       }
 }
 
+// Plain f32 NT GEMM whose k-loop stops at a device-side bound (*kdyn = index of the last non-zero column of A):
+// XH32 = LAM32 * Pinv32 of the f32 active-set rounds.
+template <int NB>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kdyn_k(float* __restrict__ C, size_t ldc,
+                                                          const float* __restrict__ A, size_t lda,
+                                                          const float* __restrict__ B, size_t ldb,
+                                                          int K, const int* __restrict__ kdyn) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using Cf = TileCfg<NB>;
+  K = min(K, ((*kdyn + KC) / KC) * KC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * NB, n0 = blockIdx.x * NB;
+  f32x16 acc[Cf::MT][Cf::MT];
+  zero_acc<NB>(acc);
+  PlainOp a{A + (size_t)m0 * lda, lda};
+  PlainOp b{B + (size_t)n0 * ldb, ldb};
+  tile_gemm_nt<NB>(acc, a, b, K, lds, false);
+#pragma unroll
+  for (int mi = 0; mi < Cf::MT; ++mi)
+#pragma unroll
+    for (int mj = 0; mj < Cf::MT; ++mj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * Cf::WT + mi * 32 + acc_row(r, lane);
+        const int col = n0 + wc * Cf::WT + mj * 32 + acc_col(lane);
+        C[(size_t)row * ldc + col] = acc[mi][mj][r];
+      }
+}
+
 // f64 NT GEMM on v_mfma_f64_16x16x4_f64.  M, N multiples of 64, K multiple of 16.
 // 256 threads = 2 x 2 waves, each wave a 32 x 32 block = 2 x 2 MFMA tiles (4 f64 results per
 // lane and tile; f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg).  K-chunks of 16

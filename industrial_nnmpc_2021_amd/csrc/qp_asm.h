@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace nnmpc {
 
@@ -42,7 +43,8 @@ constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not ce
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
 // ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
 __host__ __device__ constexpr int asm_list_counter(int list) { return list < ASM_NBIN ? 4 + list : ASM_CNT_F32 + list - ASM_NBIN; }
-constexpr int ASM_NSCAN = ASM_NLIST + 3;  // scan columns: running, large sets, the lists, max active index
+constexpr int ASM_NSCAN = ASM_NLIST + 4;  // scan columns: fp64 rows, large sets, the lists, f32 rows, max active index
+constexpr int ASM_CNT_ROWS32 = 15; // counters[15]: rows of LAM32 / XH32 handed out ([2]: rows of LAM / XH)
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
 
 struct AsmDev {
@@ -75,6 +77,9 @@ struct AsmDev {
   int* row;                        // [nseg] row of lam / xh this round: the running problems are packed into rows
                                    // 0..nrun-1 (counters[2]), so the GEMM only covers those
   double tqmax;                    // max |tq| entry: |q|_inf <= tqmax |x0|_1 (q itself is only formed for the full check)
+  unsigned char* rowk;             // [nseg] 1: this round's row is one of LAM32 / XH32 (f32 solve and GEMM), 0: of LAM / XH
+  float* lam32;                    // [rows] f32 multiplier rows (GEMM operand of the f32 rounds)
+  const float* xh32;               // [rows] = lam32 * H (f32)
   unsigned char* prec;             // [nseg] 0: rounds in f32 until the set settles, 1: fp64 (only these results are accepted)
   int* ninf_best;                  // [nseg] smallest number of infeasible indices seen so far (exchange rule of asm_update_k)
   unsigned char* alpha;            // [nseg] rounds of grace left before single exchanges
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // and a place in the list of their size class -- by exclusive scans over the problems (chunks of 1024 per
 // workgroup: ranks inside the chunk from wave ballots, then the chunk totals) instead of one same-address
 // atomic per problem, which cost more than the factorisations' launch.
-// counters: [0] = [2] = nrun, [1] sets too large for LDS, [3] largest active variable index, [4 + b] length
+// counters: [2] / [ASM_CNT_ROWS32] running problems solved in fp64 / f32 this round (the host adds them up), [1] sets too large for LDS, [3] largest active variable index, [4 + b] length
 // of size-class list b.  counters[ASM_CNT_WIDE] (filled by asm_update_k, consumed by asm_wide_k earlier in
 // the round) is reset here.
 __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + list otherwise
@@ -208,11 +213,13 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   int kl = 0;
   if (run) { const int m = d.mg[p]; if (m > 0) kl = d.idxg[(size_t)p * d.max_active + m - 1]; }
   const unsigned long long lt = (1ull << lane) - 1ull;
+  const bool r32 = col > ASM_NBIN;                           // solved in f32 this round: row of LAM32 / XH32
+  const int rcol = r32 ? ASM_NSCAN - 2 : 0;
   int myrank = 0, myrow = 0;
   {
-    const unsigned long long mk = __ballot(run);
-    myrow = __popcll(mk & lt);
-    if (lane == 0) wtot[0][wave] = __popcll(mk);
+    const unsigned long long m64 = __ballot(run && !r32), m32 = __ballot(r32);
+    myrow = __popcll((r32 ? m32 : m64) & lt);
+    if (lane == 0) { wtot[0][wave] = __popcll(m64); wtot[ASM_NSCAN - 2][wave] = __popcll(m32); }
   }
 #pragma unroll
   for (int c = 0; c <= ASM_NLIST; ++c) {
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   if (lane == 0) wtot[ASM_NSCAN - 1][wave] = kl;
   __syncthreads();
   if (run) {
-    for (int w = 0; w < wave; ++w) { myrow += wtot[0][w]; myrank += wtot[1 + col][w]; }
+    for (int w = 0; w < wave; ++w) { myrow += wtot[rcol][w]; myrank += wtot[1 + col][w]; }
     d.row[p] = myrow;
     d.lrank[p] = myrank;
   }
@@ -251,8 +258,9 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
         d.counters[ASM_CNT_WIDE] = 0;
       } else {
         const int tot = t + d.ctot[(size_t)blockIdx.x * ASM_NSCAN + tid];
-        if (tid == 0) { d.counters[0] = tot; d.counters[2] = tot; }
+        if (tid == 0) d.counters[2] = tot;
         else if (tid == 1) d.counters[1] = tot;
+        else if (tid == ASM_NSCAN - 2) d.counters[ASM_CNT_ROWS32] = tot;
         else d.counters[asm_list_counter(tid - 2)] = tot;
       }
     }
@@ -261,7 +269,9 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   bool run;
   const int col = asm_scan_col(d, p, run);
   if (!run) return;
-  d.row[p] += base[0];
+  const bool r32 = col > ASM_NBIN;
+  d.row[p] += base[r32 ? ASM_NSCAN - 2 : 0];
+  d.rowk[p] = r32;
   const int pos = base[1 + col] + d.lrank[p];
   if (col == 0) d.biglist[pos] = p;
   else d.binlist[(size_t)(col - 1) * d.nseg + pos] = p;
@@ -755,11 +765,12 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
     lam[K] = xsum4<T>(part);
     __builtin_amdgcn_sched_barrier(0);
   }
-  double* lrow = d.lam + (size_t)d.row[p] * d.np;
+  using LT = typename std::conditional<N::F32, float, double>::type;   // f32 rounds: row of LAM32 (f32 GEMM)
+  LT* lrow = (N::F32 ? (LT*)d.lam32 : (LT*)d.lam) + (size_t)d.row[p] * d.np;
 #pragma unroll
   for (int I = 0; I < MB; ++I) {
     const int i = 16 * I + li;
-    if (lq == 0 && i < m) lrow[idx[i]] = (double)lam[I];
+    if (lq == 0 && i < m) lrow[idx[i]] = (LT)lam[I];
   }
 }
 
@@ -832,7 +843,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
     if (lane == 0) d.redo[p] = 0;                            // the same set runs again in fp64
     return;
   }
-  const bool f32_phase = d.prec[p] == 0;                     // multipliers only good enough to move the set
+  const bool f32_phase = d.rowk[p] != 0;                     // f32 solve and GEMM: only good enough to move the set
   const size_t o = (size_t)p * d.np, orow = (size_t)d.row[p] * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
   const int W = min(d.W, d.n);                               // every active bound lies inside the window
@@ -852,7 +863,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
       if (st[r]) continue;
       const int k = r % d.nu;
       const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
-      const double x = d.xunc[o + r] - d.xh[orow + r];
+      const double x = d.xunc[o + r] - (f32_phase ? (double)d.xh32[orow + r] : d.xh[orow + r]);
       const int ns = x > ub + d.bound_tol ? 1 : (x < lb - d.bound_tol ? 2 : 0);
       if (!ns) continue;
       if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)r; ch_s[wv][chg][lane] = (unsigned char)ns; } ++chg; rmax = max(rmax, r); }
@@ -860,7 +871,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
     }
     for (int i = lane; i < m; i += 64) {                     // active bounds: multiplier signs (keep iff multiplier > 0)
       const int a = idx[i], sa = st[a];
-      const double l = d.lam[orow + a];
+      const double l = f32_phase ? (double)d.lam32[orow + a] : d.lam[orow + a];
       if (mode == 0) { l1 += fabs(l); lmin = fmin(lmin, fabs(l)); }
       if (!((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0))) continue;
       if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)a; ch_s[wv][chg][lane] = 0; } ++chg; rmax = max(rmax, a); }
@@ -907,9 +918,12 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
     double* lw = settle_wide ? d.lamw + (size_t)wrow * d.np : nullptr;
     for (int i = lane; i < m; i += 64) {
       const int a = idx[i];
-      const double l = d.lam[orow + a];
-      d.lam[orow + a] = 0.0;
-      if (lw) lw[a] = l;
+      if (f32_phase) d.lam32[orow + a] = 0.f;                // (never settles: lw is null)
+      else {
+        const double l = d.lam[orow + a];
+        d.lam[orow + a] = 0.0;
+        if (lw) lw[a] = l;
+      }
     }
   }
   bool sure = false;

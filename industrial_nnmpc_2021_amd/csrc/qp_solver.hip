@@ -643,7 +643,8 @@ struct nnmpc_qp {
   int* asm_wlist;
   unsigned char* asm_st;
   int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row, *asm_lrank, *asm_ctot;
-  unsigned char *asm_prec, *asm_redo, *asm_alpha;
+  unsigned char *asm_prec, *asm_redo, *asm_alpha, *asm_rowk;
+  float *asm_lam32, *asm_xh32, *H32;
   int* asm_ninf;
   double tqmax;         // max |tq| entry
   int asm_pool;
@@ -879,7 +880,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
@@ -912,7 +913,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    const int nrun = cnt[0];
+    const int n64 = cnt[2], n32 = cnt[ASM_CNT_ROWS32], nrun = n64 + n32;   // solved in fp64 / f32 this round
     if (h->profiling)                                   // flops of the full-width pass that opened this round
       h->stats.asm_gemm_flops += 2.0 * h->np * (double)std::min(h->np, ((kprev + 16) / 16) * 16) * cnt[ASM_CNT_WIDE + 1];
     kprev = cnt[3];
@@ -944,11 +945,19 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       if (nbig) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     {
-      // the running problems sit in rows 0..nrun-1 of LAM (asm_bins_k), the rest of the last 64-row block is zero;
-      // algorithmic flops of LAM * Pinv: 2 * n * (columns up to the last active bound) per running problem
+      // the running problems sit in rows 0..n64-1 of LAM (fp64 solves) and 0..n32-1 of LAM32 (f32 solves), the rest
+      // of the last row block is zero; algorithmic flops of LAM * Pinv: 2 * columns * (k up to the last active bound)
+      // per running problem
       EvScope es(h, 5, 2.0 * a.W * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun);
-      gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((nrun + 127) / 128) * 128, a.W, h->np, nullptr, 0,
-             h->asm_counters + 3);
+      if (n64)
+        gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((n64 + 127) / 128) * 128, a.W, h->np, nullptr, 0,
+               h->asm_counters + 3);
+      if (n32 && a.W % 128 == 0)
+        hipLaunchKernelGGL((gemm_nt_f32_kdyn_k<128>), dim3(a.W / 128, (n32 + 127) / 128), dim3(256), TileCfg<128>::LDS_FLOATS * 4, s,
+                           h->asm_xh32, (size_t)h->np, h->asm_lam32, (size_t)h->np, h->H32, (size_t)h->np, h->np, h->asm_counters + 3);
+      else if (n32)
+        hipLaunchKernelGGL((gemm_nt_f32_kdyn_k<64>), dim3(a.W / 64, (n32 + 63) / 64), dim3(256), TileCfg<64>::LDS_FLOATS * 4, s,
+                           h->asm_xh32, (size_t)h->np, h->asm_lam32, (size_t)h->np, h->H32, (size_t)h->np, h->np, h->asm_counters + 3);
     }
     {
       EvScope es(h, 6, 0.0);
@@ -1074,6 +1083,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32b_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32B_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_kdyn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
   if (set_lds_attrs<128>() != 0 || set_lds_attrs<64>() != 0) {
@@ -1101,7 +1111,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     // populated last rounds of the active-set pass.
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)12e9;
-    long long cap = (long long)(0.25 * (double)free_b / (12.0 * np + 48.0 * np + n + 4.0 * o.asm_max_active + 64.0));
+    long long cap = (long long)(0.25 * (double)free_b / (12.0 * np + 56.0 * np + n + 4.0 * o.asm_max_active + 64.0));
     cap = std::max<long long>(cap, S);
     cap = std::min<long long>(cap, 1 << 20);
     h->seg_max = (int)((cap / 128) * 128);
@@ -1114,12 +1124,12 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.lb64, (size_t)S * nu); A_(d.ub64, (size_t)S * nu);
   A_(d.slot_prob, S); A_(d.age, S); A_(d.next_prob, 1);
   h->asm_pool = 256;
-  A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka);
+  A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka); A_(h->H32, (size_t)np * np);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_lamw, G * np); A_(h->asm_xhw, G * np); A_(h->asm_wlist, G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NLIST * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_work, 2 * G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_work, 2 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
@@ -1206,6 +1216,11 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
     for (int k = 0; k < n_aug; ++k) kk[(size_t)r * ka + k] = Kunc[(size_t)r * n_aug + k];
   }
   HIPCHK(hipMemcpy(h->H64, hh.data(), hh.size() * 8, hipMemcpyHostToDevice));
+  {
+    std::vector<float> h32(hh.size());
+    for (size_t i = 0; i < hh.size(); ++i) h32[i] = (float)hh[i];
+    HIPCHK(hipMemcpy(h->H32, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
   // ---- verify the inverse once, on the device copies the solves will use:
   //      E2 = P Pinv - I,  E1 = P Kunc + tq;  their maxima feed the per-problem certificate

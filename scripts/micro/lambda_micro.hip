@@ -59,6 +59,8 @@ int main(int argc, char** argv) {
   d.binlist = dbin; d.idxg = didx; d.mg = dmg;
   unsigned char *dprec, *dredo; CK(hipMalloc(&dprec, nseg)); CK(hipMemset(dprec, 0, nseg)); CK(hipMalloc(&dredo, nseg)); CK(hipMemset(dredo, 0, nseg));
   d.prec = dprec; d.redo = dredo;
+  float* dlam32; CK(hipMalloc(&dlam32, xunc.size() * 4)); CK(hipMemset(dlam32, 0, xunc.size() * 4)); d.lam32 = dlam32;
+  unsigned char* drowk; CK(hipMalloc(&drowk, nseg)); CK(hipMemset(drowk, 0, nseg)); d.rowk = drowk;
   int* drow; CK(hipMalloc(&drow, nseg * 4)); CK(hipMemcpy(drow, list.data(), nseg * 4, hipMemcpyHostToDevice)); d.row = drow;
   const int mbc = asm_bin_cap(bin) / 16;
   const int lds_tile = (asm_bin_cap(bin) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
@@ -88,6 +90,11 @@ int main(int argc, char** argv) {
   double worst = 0.0;
   for (int pp = 0; pp < 2; ++pp) {
     const int p = pp == 0 ? 0 : nseg - 1;
+    if (variant == 2) {
+      std::vector<float> l32(np);
+      CK(hipMemcpy(l32.data(), dlam32 + (size_t)p * np, np * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < np; ++i) lam[i] = l32[i];
+    } else
     CK(hipMemcpy(lam.data(), dlam + (size_t)p * np, np * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < m; ++i) {
       const int a = idx[(size_t)p * max_active + i];
