@@ -81,6 +81,7 @@ struct AsmDev {
   float* lam32;                    // [rows] f32 multiplier rows (GEMM operand of the f32 rounds)
   const float* xh32;               // [rows] = lam32 * H (f32)
   unsigned char* prec;             // [nseg] 0: rounds in f32 until the set settles, 1: fp64 (only these results are accepted)
+  int* hi;                         // [nseg] no bound at or beyond this index is active (asm_count_k scans [0, hi) only)
   int* ninf_best;                  // [nseg] smallest number of infeasible indices seen so far (exchange rule of asm_update_k)
   unsigned char* alpha;            // [nseg] rounds of grace left before single exchanges
   unsigned char* redo;             // [nseg] set by the f32 kernel when S is not positive definite in f32: the round is void
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     d.prec[p] = (d.use_f32 && !d.guess) ? 0 : 1;       // a caller's guess is expected to be right: confirm it in fp64 at once
     d.redo[p] = 0;
     d.ninf_best[p] = 0x7fffffff; d.alpha[p] = ASM_GRACE;
+    d.hi[p] = wi;
   }
 }
 
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   if (d.state[p] != ASM_RUN) return;
   const unsigned char* st = d.st + (size_t)p * d.n;
   const bool words = (d.n & 3) == 0;                         // rows of st are then 4-byte aligned: 4 bounds per load
-  const int nw = words ? d.n >> 2 : d.n;                     // items (dwords or bytes), a contiguous run per thread
+  const int hi = min(d.n, d.hi[p]);                          // nothing is active at or beyond hi
+  const int nw = words ? (hi + 3) >> 2 : hi;                 // items (dwords or bytes), a contiguous run per thread
   const int per = (nw + 255) / 256;
   const int j0 = min(nw, tid * per), j1 = min(nw, j0 + per);
   const uint32_t* sw = reinterpret_cast<const uint32_t*>(st);
@@ -948,6 +951,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   if (lane == 0) {
     const int rd = d.rounds[p] + 1;
     d.rounds[p] = rd;
+    if (tot > 0 && d.hi[p] < W) d.hi[p] = W;                 // bounds inside the window may have joined
     if (tot == 0 && f32_phase) d.prec[p] = 1;
     if (settle_wide) d.state[p] = ASM_WIDE;
     else if (settled) {
@@ -1019,6 +1023,7 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
     } else {
       d.state[p] = d.rounds[p] >= d.max_rounds ? ASM_FALLBACK : ASM_RUN;
       d.ninf_best[p] = 0x7fffffff; d.alpha[p] = ASM_GRACE;          // new bounds joined: the exchange rule starts afresh
+      d.hi[p] = d.n;                                                // ... anywhere
     }
   }
 }
