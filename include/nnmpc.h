@@ -71,6 +71,8 @@ typedef struct {
                                 single-exchange fallback against cycling may take one round per bound) */
   int32_t asm_f32_rounds;    /* 0 = the rounds run in f32 until a problem's set settles, then in fp64 (only fp64
                                 results are accepted); < 0 = fp64 from the first round */
+  int32_t seg_max;           /* problems per segment (one lock-step pass; ~0.3 MB of workspace each at n = 4480);
+                                0 = as many as a quarter of the free HBM holds (at most 2^20) */
   float ipm_tol;             /* PDIP exit, objective scaled by 1/median(diag P):
                                 |r_d|_inf and mu <= tol*max(1,|q|_inf); 0 = 1e-2 */
   double refine_tol;         /* PCG exit: |step|_inf <= tol*max(1,|x|_inf); 0 = 1e-10 */

@@ -1112,6 +1112,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)12e9;
     long long cap = (long long)(0.25 * (double)free_b / (12.0 * np + 56.0 * np + n + 4.0 * o.asm_max_active + 64.0));
+    if (o.seg_max > 0) cap = std::min<long long>(cap, o.seg_max);
     cap = std::max<long long>(cap, S);
     cap = std::min<long long>(cap, 1 << 20);
     h->seg_max = (int)((cap / 128) * 128);

@@ -98,3 +98,20 @@ def test_cdu_size_pdip_path_and_fallback_agree_with_active_set_pass():
     st = qp3.stats()
     assert (fb["status"] == 0).all() and st["asm_solved"] < B and st["factorizations"] > 0
     assert np.abs(fb["u"] - fast["u"]).max() < 1e-7 and np.array_equal(fb["active"], fast["active"])
+
+
+@pytest.mark.parametrize("method", ["auto", "pdip"])
+def test_batches_larger_than_a_segment(method):
+    """seg_max caps the problems per lock-step pass: a batch of several segments (with a ragged last one) must give
+    exactly what one big segment gives, problem by problem."""
+    B = 1000
+    pl, P, tq, nu, x0, lb, ub, qp1 = _setup("mini_cdu", B, 33, 2.5, max_batch=128, method=method)
+    ref = qp1.solve_batch(x0, lb, ub)
+    assert (ref["status"] == 0).all()
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    qp2 = BatchedBoxQP(P, tq, nu, max_batch=128, method=method, seg_max=384)
+    out = qp2.solve_batch(x0, lb, ub)
+    assert (out["status"] == 0).all()
+    assert np.array_equal(out["active"], ref["active"])
+    assert np.abs(out["u"] - ref["u"]).max() <= 1e-9
+    _kkt(P, tq, nu, pl["N"], x0, lb, ub, out, 1e-7)
