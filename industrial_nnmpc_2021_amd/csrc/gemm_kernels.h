@@ -38,16 +38,22 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_k(float* __restrict__ C, size
       }
 }
 
-// Plain f32 NT GEMM whose k-loop stops at a device-side bound (*kdyn = index of the last non-zero column of A):
+// Plain f32 NT GEMM whose k-loop stops at a device-side bound (kdyn: index of the last non-zero column of A, per
+// launch or per row block):
 // XH32 = LAM32 * Pinv32 of the f32 active-set rounds.
 template <int NB>
 __global__ __launch_bounds__(256) void gemm_nt_f32_kdyn_k(float* __restrict__ C, size_t ldc,
                                                           const float* __restrict__ A, size_t lda,
                                                           const float* __restrict__ B, size_t ldb,
-                                                          int K, const int* __restrict__ kdyn) {
+                                                          int K, const int* __restrict__ kdyn, int kper) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using Cf = TileCfg<NB>;
-  K = min(K, ((*kdyn + KC) / KC) * KC);
+  {
+    // kper = 0: one bound for the launch; else kper consecutive entries per row block (64-row granularity)
+    int kl = kdyn[kper * blockIdx.y];
+    for (int i = 1; i < kper; ++i) kl = max(kl, kdyn[kper * blockIdx.y + i]);
+    K = min(K, ((kl + KC) / KC) * KC);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.y * NB, n0 = blockIdx.x * NB;
@@ -81,11 +87,16 @@ static __global__ __launch_bounds__(256) void gemm_nt_f64_k(double* __restrict__
                                                      const double* __restrict__ B, size_t ldb,
                                                      int K, const int* __restrict__ rowphase,
                                                      int want, const int* __restrict__ kdyn = nullptr,
-                                                     const int* __restrict__ mdyn = nullptr) {
+                                                     const int* __restrict__ mdyn = nullptr, int kper = 0) {
   constexpr int LD = 18;
   // kdyn (nullable): device-side bound on the non-zero columns of A (last non-zero column index);
-  // the k-loop stops there -- LAM rows of the active-set pass are zero beyond the last active bound
-  if (kdyn) K = min(K, ((*kdyn + 16) / 16) * 16);
+  // the k-loop stops there -- LAM rows of the active-set pass are zero beyond the last active bound.
+  // kper = 0: one bound for the launch; else kper consecutive entries per row block (64-row granularity)
+  if (kdyn) {
+    int kl = kdyn[kper * blockIdx.y];
+    for (int i = 1; i < kper; ++i) kl = max(kl, kdyn[kper * blockIdx.y + i]);
+    K = min(K, ((kl + 16) / 16) * 16);
+  }
   __shared__ __attribute__((aligned(16))) double As[2][64 * LD];
   __shared__ __attribute__((aligned(16))) double Bs[2][64 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,10 +175,14 @@ static __global__ __launch_bounds__(256, 2) void gemm_nt_f64_128_k(double* __res
                                                                   const double* __restrict__ B, size_t ldb,
                                                                   int K, const int* __restrict__ rowphase,
                                                                   int want, const int* __restrict__ kdyn = nullptr,
-                                                                  const int* __restrict__ mdyn = nullptr) {
+                                                                  const int* __restrict__ mdyn = nullptr, int kper = 0) {
   constexpr int LD = 18, TS = 128 * LD;
   extern __shared__ __attribute__((aligned(16))) double sm128[];   // [2][A 128 x LD | B 128 x LD]
-  if (kdyn) K = min(K, ((*kdyn + 16) / 16) * 16);
+  if (kdyn) {
+    int kl = kdyn[kper * blockIdx.y];
+    for (int i = 1; i < kper; ++i) kl = max(kl, kdyn[kper * blockIdx.y + i]);
+    K = min(K, ((kl + 16) / 16) * 16);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;

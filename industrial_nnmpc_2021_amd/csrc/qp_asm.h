@@ -43,7 +43,10 @@ constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not ce
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
 // ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
 __host__ __device__ constexpr int asm_list_counter(int list) { return list < ASM_NBIN ? 4 + list : ASM_CNT_F32 + list - ASM_NBIN; }
-constexpr int ASM_NSCAN = ASM_NLIST + 4;  // scan columns: fp64 rows, large sets, the lists, f32 rows, max active index
+constexpr int ASM_NKG = 3;         // rows of a round are ordered by the last active stage (groups: <= median, +1, beyond),
+                                   // so that a 128-row block of the GEMM stops its k-loop at ITS last active bound
+constexpr int ASM_NSCAN = ASM_NLIST + 3 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, sum and max of
+                                                        // the last active indices
 constexpr int ASM_CNT_ROWS32 = 15; // counters[15]: rows of LAM32 / XH32 handed out ([2]: rows of LAM / XH)
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
 
@@ -81,6 +84,9 @@ struct AsmDev {
   float* lam32;                    // [rows] f32 multiplier rows (GEMM operand of the f32 rounds)
   const float* xh32;               // [rows] = lam32 * H (f32)
   unsigned char* prec;             // [nseg] 0: rounds in f32 until the set settles, 1: fp64 (only these results are accepted)
+  int* kblk;                       // [2][nkblk / 2] last active bound per 64-row block of LAM / LAM32 (k-range of the GEMMs)
+  int nkblk;
+  int kref;                        // last round's overall last active bound (row grouping of asm_bins)
   int* hi;                         // [nseg] no bound at or beyond this index is active (asm_count_k scans [0, hi) only)
   int* ninf_best;                  // [nseg] smallest number of infeasible indices seen so far (exchange rule of asm_update_k)
   unsigned char* alpha;            // [nseg] rounds of grace left before single exchanges
@@ -199,6 +205,9 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // counters: [2] / [ASM_CNT_ROWS32] running problems solved in fp64 / f32 this round (the host adds them up), [1] sets too large for LDS, [3] largest active variable index, [4 + b] length
 // of size-class list b.  counters[ASM_CNT_WIDE] (filled by asm_update_k, consumed by asm_wide_k earlier in
 // the round) is reset here.
+// scan columns: 0 large sets, 1 + list, ASM_COL_ROW + prec * ASM_NKG + group (rows of LAM / LAM32), then the sum of
+// (last active index + 1) and the max index
+constexpr int ASM_COL_ROW = 1 + ASM_NLIST;
 __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + list otherwise
   run = p < d.nseg && d.state[p] == ASM_RUN;
   if (!run) return -1;
@@ -207,34 +216,42 @@ __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {
   const int b = max((m + 15) / 16, 4) - 4;
   return 1 + (d.prec[p] == 0 ? ASM_NBIN + b : b);
 }
+// group by the stage of the last active bound, relative to last round's overall last stage (d.kref)
+__device__ __forceinline__ int asm_kgroup(const AsmDev& d, int kl) {
+  const int st10 = 10 * (kl / d.nu), sref = d.kref / d.nu;
+  return st10 <= 7 * sref ? 0 : (st10 <= 8 * sref ? 1 : 2);
+}
 __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   __shared__ int wtot[ASM_NSCAN][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = blockIdx.x * 1024 + tid;
+  for (int i = p; i < d.nkblk; i += gridDim.x * 1024) d.kblk[i] = 0;      // filled by asm_bins_b_k
   bool run;
   const int col = asm_scan_col(d, p, run);
   int kl = 0;
   if (run) { const int m = d.mg[p]; if (m > 0) kl = d.idxg[(size_t)p * d.max_active + m - 1]; }
   const unsigned long long lt = (1ull << lane) - 1ull;
   const bool r32 = col > ASM_NBIN;                           // solved in f32 this round: row of LAM32 / XH32
-  const int rcol = r32 ? ASM_NSCAN - 2 : 0;
+  const int rcol = run ? ASM_COL_ROW + (r32 ? ASM_NKG : 0) + asm_kgroup(d, kl) : -1;
   int myrank = 0, myrow = 0;
-  {
-    const unsigned long long m64 = __ballot(run && !r32), m32 = __ballot(r32);
-    myrow = __popcll((r32 ? m32 : m64) & lt);
-    if (lane == 0) { wtot[0][wave] = __popcll(m64); wtot[ASM_NSCAN - 2][wave] = __popcll(m32); }
+#pragma unroll
+  for (int c = 0; c < 2 * ASM_NKG; ++c) {
+    const unsigned long long mk = __ballot(rcol == ASM_COL_ROW + c);
+    if (rcol == ASM_COL_ROW + c) myrow = __popcll(mk & lt);
+    if (lane == 0) wtot[ASM_COL_ROW + c][wave] = __popcll(mk);
   }
 #pragma unroll
   for (int c = 0; c <= ASM_NLIST; ++c) {
     const unsigned long long mk = __ballot(col == c);
     if (col == c) myrank = __popcll(mk & lt);
-    if (lane == 0) wtot[1 + c][wave] = __popcll(mk);
+    if (lane == 0) wtot[c][wave] = __popcll(mk);
   }
-  for (int off = 32; off > 0; off >>= 1) kl = max(kl, __shfl_xor(kl, off));
-  if (lane == 0) wtot[ASM_NSCAN - 1][wave] = kl;
+  int km = kl, ks = run ? kl + 1 : 0;                        // ks: columns of LAM this row really has
+  for (int off = 32; off > 0; off >>= 1) { km = max(km, __shfl_xor(km, off)); ks += __shfl_xor(ks, off); }
+  if (lane == 0) { wtot[ASM_NSCAN - 1][wave] = km; wtot[ASM_NSCAN - 2][wave] = ks; }
   __syncthreads();
   if (run) {
-    for (int w = 0; w < wave; ++w) { myrow += wtot[rcol][w]; myrank += wtot[1 + col][w]; }
+    for (int w = 0; w < wave; ++w) { myrow += wtot[rcol][w]; myrank += wtot[col][w]; }
     d.row[p] = myrow;
     d.lrank[p] = myrank;
   }
@@ -246,36 +263,42 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   }
 }
 __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
-  __shared__ int base[ASM_NSCAN];
+  __shared__ int base[ASM_NSCAN], total[ASM_NSCAN];
   const int tid = threadIdx.x;
   const int p = blockIdx.x * 1024 + tid;
   if (tid < ASM_NSCAN) {
-    int t = 0;
-    if (tid == ASM_NSCAN - 1) { for (int j = 0; j < (int)gridDim.x; ++j) t = max(t, d.ctot[(size_t)j * ASM_NSCAN + tid]); }
-    else { for (int j = 0; j < (int)blockIdx.x; ++j) t += d.ctot[(size_t)j * ASM_NSCAN + tid]; }
-    base[tid] = t;
-    if (blockIdx.x == gridDim.x - 1) {                       // the last chunk knows the totals
-      if (tid == ASM_NSCAN - 1) {
-        d.counters[3] = t;
-        d.counters[ASM_CNT_WIDE + 1] = d.counters[ASM_CNT_WIDE];   // how many asm_wide_k just handled (statistics)
-        d.counters[ASM_CNT_WIDE] = 0;
-      } else {
-        const int tot = t + d.ctot[(size_t)blockIdx.x * ASM_NSCAN + tid];
-        if (tid == 0) d.counters[2] = tot;
-        else if (tid == 1) d.counters[1] = tot;
-        else if (tid == ASM_NSCAN - 2) d.counters[ASM_CNT_ROWS32] = tot;
-        else d.counters[asm_list_counter(tid - 2)] = tot;
-      }
+    int t = 0, all = 0;
+    if (tid == ASM_NSCAN - 1) { for (int j = 0; j < (int)gridDim.x; ++j) t = max(t, d.ctot[(size_t)j * ASM_NSCAN + tid]); all = t; }
+    else {
+      for (int j = 0; j < (int)gridDim.x; ++j) { const int v = d.ctot[(size_t)j * ASM_NSCAN + tid]; if (j < (int)blockIdx.x) t += v; all += v; }
     }
+    base[tid] = t; total[tid] = all;
   }
   __syncthreads();
+  if (blockIdx.x == gridDim.x - 1 && tid < ASM_NSCAN) {      // one workgroup publishes the totals
+    if (tid == ASM_NSCAN - 1) {
+      d.counters[3] = total[tid];
+      d.counters[ASM_CNT_WIDE + 1] = d.counters[ASM_CNT_WIDE];   // how many asm_wide_k just handled (statistics)
+      d.counters[ASM_CNT_WIDE] = 0;
+    } else if (tid == ASM_NSCAN - 2) d.counters[0] = total[tid];   // sum of (last active index + 1): algorithmic k of the GEMM
+    else if (tid == 0) d.counters[1] = total[0];
+    else if (tid <= ASM_NLIST) d.counters[asm_list_counter(tid - 1)] = total[tid];
+    else if (tid == ASM_COL_ROW) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + g]; d.counters[2] = t; }
+    else if (tid == ASM_COL_ROW + ASM_NKG) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + ASM_NKG + g]; d.counters[ASM_CNT_ROWS32] = t; }
+  }
   bool run;
   const int col = asm_scan_col(d, p, run);
   if (!run) return;
+  const int m = d.mg[p];
+  const int kl = m > 0 ? d.idxg[(size_t)p * d.max_active + m - 1] : 0;
   const bool r32 = col > ASM_NBIN;
-  d.row[p] += base[r32 ? ASM_NSCAN - 2 : 0];
+  const int c0 = ASM_COL_ROW + (r32 ? ASM_NKG : 0), g = asm_kgroup(d, kl);
+  int row = d.row[p] + base[c0 + g];
+  for (int gg = 0; gg < g; ++gg) row += total[c0 + gg];      // rows ordered by group
+  d.row[p] = row;
   d.rowk[p] = r32;
-  const int pos = base[1 + col] + d.lrank[p];
+  atomicMax(&d.kblk[(r32 ? d.nkblk / 2 : 0) + (row >> 6)], kl);   // last active bound of this 64-row block
+  const int pos = base[col] + d.lrank[p];
   if (col == 0) d.biglist[pos] = p;
   else d.binlist[(size_t)(col - 1) * d.nseg + pos] = p;
 }

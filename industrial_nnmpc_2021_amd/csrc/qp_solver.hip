@@ -645,7 +645,7 @@ struct nnmpc_qp {
   int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row, *asm_lrank, *asm_ctot;
   unsigned char *asm_prec, *asm_redo, *asm_alpha, *asm_rowk;
   float *asm_lam32, *asm_xh32, *H32;
-  int *asm_ninf, *asm_hi;
+  int *asm_ninf, *asm_hi, *asm_kblk;
   double tqmax;         // max |tq| entry
   int asm_pool;
   double asm_e1max, asm_e2max;
@@ -734,14 +734,15 @@ void gemm32(nnmpc_qp* h, float* C, size_t ldc, const float* A, size_t lda, const
 }
 void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, const double* B,
             size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0,
-            const int* kdyn = nullptr, const int* mdyn = nullptr) {
+            const int* kdyn = nullptr, const int* mdyn = nullptr, bool kblocks = false) {
+  // kblocks: kdyn holds one bound per 64 rows of A (else one for the launch)
   if (M % 128 == 0 && N % 128 == 0) {
     hipLaunchKernelGGL(gemm_nt_f64_128_k, dim3(N / 128, M / 128), dim3(256), GEMM64_128_LDS, h->stream, C, ldc, A, lda, B, ldb, K,
-                       rowphase, want, kdyn, mdyn);
+                       rowphase, want, kdyn, mdyn, kblocks ? 2 : 0);
     return;
   }
   dim3 grid(N / 64, M / 64);
-  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want, kdyn, mdyn);
+  hipLaunchKernelGGL(gemm_nt_f64_k, grid, dim3(256), 0, h->stream, C, ldc, A, lda, B, ldb, K, rowphase, want, kdyn, mdyn, kblocks ? 1 : 0);
 }
 
 template <int NB>
@@ -880,7 +881,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
@@ -905,6 +906,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       EvScope es(h, 6, 0.0);
       hipLaunchKernelGGL(asm_wide_k, dim3(prev_run), dim3(256), 0, s, a);
     }
+    a.kref = kprev;
     {
       EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
       hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
@@ -948,16 +950,18 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // the running problems sit in rows 0..n64-1 of LAM (fp64 solves) and 0..n32-1 of LAM32 (f32 solves), the rest
       // of the last row block is zero; algorithmic flops of LAM * Pinv: 2 * columns * (k up to the last active bound)
       // per running problem
-      EvScope es(h, 5, 2.0 * a.W * (double)std::min(h->np, ((cnt[3] + 16) / 16) * 16) * nrun);
+      // algorithmic flops: 2 * window columns * (own last active bound + 1) per running problem (cnt[0] is their sum)
+      EvScope es(h, 5, 2.0 * a.W * (double)cnt[0]);
       if (n64)
         gemm64(h, h->asm_xh, h->np, h->asm_lam, h->np, h->H64, h->np, ((n64 + 127) / 128) * 128, a.W, h->np, nullptr, 0,
-               h->asm_counters + 3);
+               h->asm_kblk, nullptr, true);
+      // (rows are ordered by their last active stage: every 64-row block has its own k-range, asm_bins_b_k)
       if (n32 && a.W % 128 == 0)
         hipLaunchKernelGGL((gemm_nt_f32_kdyn_k<128>), dim3(a.W / 128, (n32 + 127) / 128), dim3(256), TileCfg<128>::LDS_FLOATS * 4, s,
-                           h->asm_xh32, (size_t)h->np, h->asm_lam32, (size_t)h->np, h->H32, (size_t)h->np, h->np, h->asm_counters + 3);
+                           h->asm_xh32, (size_t)h->np, h->asm_lam32, (size_t)h->np, h->H32, (size_t)h->np, h->np, h->asm_kblk + a.nkblk / 2, 2);
       else if (n32)
         hipLaunchKernelGGL((gemm_nt_f32_kdyn_k<64>), dim3(a.W / 64, (n32 + 63) / 64), dim3(256), TileCfg<64>::LDS_FLOATS * 4, s,
-                           h->asm_xh32, (size_t)h->np, h->asm_lam32, (size_t)h->np, h->H32, (size_t)h->np, h->np, h->asm_counters + 3);
+                           h->asm_xh32, (size_t)h->np, h->asm_lam32, (size_t)h->np, h->H32, (size_t)h->np, h->np, h->asm_kblk + a.nkblk / 2, 1);
     }
     {
       EvScope es(h, 6, 0.0);
@@ -1130,7 +1134,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_lamw, G * np); A_(h->asm_xhw, G * np); A_(h->asm_wlist, G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NLIST * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_work, 2 * G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 2 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
