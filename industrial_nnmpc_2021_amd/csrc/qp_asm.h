@@ -34,11 +34,15 @@ constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: 
 enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4 };   // CERT: finished and certified by the inverse-error bound
 constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
 constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds): four problems per workgroup (asm_lambda_reg_k); 6, 7: two
-constexpr int ASM_NCNT = 24;       // ints in AsmDev::counters
+constexpr int ASM_NCNT = 40;       // ints in AsmDev::counters
 constexpr int ASM_CNT_F32 = 16;    // counters[16 + b]: length of the f32 list of size class b
 constexpr int ASM_NLIST = 2 * ASM_NBIN;   // lists in AsmDev::binlist: fp64 classes, then f32 classes
 constexpr int ASM_GRACE = 10;       // rounds without a new minimum of infeasible indices before single exchanges take over
-constexpr int ASM_CNT_WIDE = 12;   // counters[12]: problems awaiting the full-width check ([13]: handled by the last asm_wide_k)
+constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last asm_wide_k (statistics)
+constexpr int ASM_CNT_WIDEG = 24;  // counters[24 + g]: problems of k-group g awaiting the full-width check (their rows of
+                                   // LAMW / XHW: region g, so that each region's GEMM stops at ITS last active bound),
+constexpr int ASM_CNT_WKMAX = 27;  // counters[27 + g]: that bound (from the group's definition; written by asm_bins_b_k),
+constexpr int ASM_CNT_WDONE = 32;  // counters[32 + g]: problems of group g handled by the last asm_wide_k (statistics)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
 // ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
@@ -99,7 +103,8 @@ struct AsmDev {
                                    // handed to the full-width check (asm_wide_k) through the lists below
   double* lamw;                    // [rows] multiplier rows of the problems awaiting the full-width check
   const double* xhw;               // [rows] = lamw * H, all columns
-  int* wlist;                      // [nseg] those problems; their number is counters[8]
+  int* wlist;                      // [ASM_NKG][wcap] those problems by k-group; their numbers are counters[ASM_CNT_WIDEG + g]
+  int wcap;                        // rows per region of lamw / xhw / wlist
   double* work;                    // [nseg][2] statistics: fp64 flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // workgroup: ranks inside the chunk from wave ballots, then the chunk totals) instead of one same-address
 // atomic per problem, which cost more than the factorisations' launch.
 // counters: [2] / [ASM_CNT_ROWS32] running problems solved in fp64 / f32 this round (the host adds them up), [1] sets too large for LDS, [3] largest active variable index, [4 + b] length
-// of size-class list b.  counters[ASM_CNT_WIDE] (filled by asm_update_k, consumed by asm_wide_k earlier in
+// of size-class list b.  counters[ASM_CNT_WIDEG..] (filled by asm_update_k, consumed by asm_wide_k earlier in
 // the round) is reset here.
 // scan columns: 0 large sets, 1 + list, ASM_COL_ROW + prec * ASM_NKG + group (rows of LAM / LAM32), then the sum of
 // (last active index + 1) and the max index
@@ -217,10 +222,16 @@ __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {
   return 1 + (d.prec[p] == 0 ? ASM_NBIN + b : b);
 }
 // group by the stage of the last active bound, relative to last round's overall last stage (d.kref)
-__device__ __forceinline__ int asm_kgroup(const AsmDev& d, int kl) {
-  const int st10 = 10 * (kl / d.nu), sref = d.kref / d.nu;
+__host__ __device__ inline int asm_kgroup_of(int kl, int kref, int nu) {
+  const int st10 = 10 * (kl / nu), sref = kref / nu;
   return st10 <= 7 * sref ? 0 : (st10 <= 8 * sref ? 1 : 2);
 }
+__host__ __device__ inline int asm_kgroup_bound_of(int g, int kref, int nu) {   // largest index a member of group g < 2 can have
+  const int sref = kref / nu;
+  return ((g == 0 ? 7 : 8) * sref / 10 + 1) * nu - 1;
+}
+__device__ __forceinline__ int asm_kgroup(const AsmDev& d, int kl) { return asm_kgroup_of(kl, d.kref, d.nu); }
+__device__ __forceinline__ int asm_kgroup_bound(const AsmDev& d, int g) { return asm_kgroup_bound_of(g, d.kref, d.nu); }
 __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   __shared__ int wtot[ASM_NSCAN][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -278,8 +289,15 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   if (blockIdx.x == gridDim.x - 1 && tid < ASM_NSCAN) {      // one workgroup publishes the totals
     if (tid == ASM_NSCAN - 1) {
       d.counters[3] = total[tid];
-      d.counters[ASM_CNT_WIDE + 1] = d.counters[ASM_CNT_WIDE];   // how many asm_wide_k just handled (statistics)
-      d.counters[ASM_CNT_WIDE] = 0;
+      int nw = 0;                                             // asm_wide_k has consumed its lists: reset them
+      for (int g = 0; g < ASM_NKG; ++g) {
+        const int c = d.counters[ASM_CNT_WIDEG + g];
+        nw += c; d.counters[ASM_CNT_WDONE + g] = c; d.counters[ASM_CNT_WIDEG + g] = 0;
+        // k-range of the next full-width pass per group: the group's last possible active bound, this round's
+        // overall last bound for the open-ended group
+        d.counters[ASM_CNT_WKMAX + g] = g == ASM_NKG - 1 ? total[tid] : min(total[tid], asm_kgroup_bound(d, g));
+      }
+      d.counters[ASM_CNT_WIDE + 1] = nw;
     } else if (tid == ASM_NSCAN - 2) d.counters[0] = total[tid];   // sum of (last active index + 1): algorithmic k of the GEMM
     else if (tid == 0) d.counters[1] = total[0];
     else if (tid <= ASM_NLIST) d.counters[asm_list_counter(tid - 1)] = total[tid];
@@ -933,7 +951,8 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   int wrow = 0;
   if (settle_wide) {
     if (lane == 0) {
-      wrow = atomicAdd(&d.counters[ASM_CNT_WIDE], 1);        // once per problem (and re-entry), not per round
+      const int kl = m > 0 ? idx[m - 1] : 0, g = asm_kgroup(d, kl);
+      wrow = g * d.wcap + atomicAdd(&d.counters[ASM_CNT_WIDEG + g], 1);   // once per problem (and re-entry), not per round
       d.wlist[wrow] = p;
     }
     wrow = __shfl(wrow, 0);
@@ -990,8 +1009,9 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
 __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
   __shared__ int cnt[4];
   __shared__ double red[12];
-  const int w = blockIdx.x, tid = threadIdx.x;
-  if (w >= d.counters[ASM_CNT_WIDE]) return;
+  const int g = blockIdx.y, tid = threadIdx.x;
+  if ((int)blockIdx.x >= d.counters[ASM_CNT_WIDEG + g]) return;
+  const int w = g * d.wcap + blockIdx.x;                     // row of LAMW / XHW: region g
   const int p = d.wlist[w];
   const size_t o = (size_t)p * d.np, orow = (size_t)w * d.np;
   // columns inside the window the problem settled in (d.W is still that round's) were evaluated by that round's

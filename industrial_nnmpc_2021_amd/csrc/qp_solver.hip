@@ -881,7 +881,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
@@ -891,21 +891,27 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   int cnt[ASM_NCNT] = {0};
   int rounds = 0;
   int prev_run = 0;                                     // upper bound of the problems awaiting the full-width check
-  int kprev = 0;
+  int kprev = 0, wide_cols = 0, kref_prev = 0;
   HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
   for (; rounds < 2 * a.max_rounds + 2; ++rounds) {
     if (prev_run) {
       // problems that settled inside last round's column window: all columns of x, once
       {
         EvScope es(h, 5, 0.0);
-        // (a.W is still last round's window: those columns are in that round's XH rows already)
+        // (a.W is still last round's window: those columns are in that round's XH rows already); one launch per
+        // k-group region: its rows share a last active bound
         const int c0 = (a.W < h->np && (h->np - a.W) % 128 == 0) ? a.W : 0;
-        gemm64(h, h->asm_xhw + c0, h->np, h->asm_lamw, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_run + 127) / 128) * 128,
-               h->np - c0, h->np, nullptr, 0, h->asm_counters + 3, h->asm_counters + ASM_CNT_WIDE);
+        for (int g = 0; g < ASM_NKG; ++g) {
+          const size_t r0 = (size_t)g * a.wcap * h->np;
+          gemm64(h, h->asm_xhw + r0 + c0, h->np, h->asm_lamw + r0, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_run + 127) / 128) * 128,
+                 h->np - c0, h->np, nullptr, 0, h->asm_counters + ASM_CNT_WKMAX + g, h->asm_counters + ASM_CNT_WIDEG + g);
+        }
+        wide_cols = h->np - c0;
       }
       EvScope es(h, 6, 0.0);
-      hipLaunchKernelGGL(asm_wide_k, dim3(prev_run), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(asm_wide_k, dim3(prev_run, ASM_NKG), dim3(256), 0, s, a);
     }
+    kref_prev = a.kref;
     a.kref = kprev;
     {
       EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
@@ -917,7 +923,12 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     HIPCHK(hipStreamSynchronize(s));
     const int n64 = cnt[2], n32 = cnt[ASM_CNT_ROWS32], nrun = n64 + n32;   // solved in fp64 / f32 this round
     if (h->profiling)                                   // flops of the full-width pass that opened this round
-      h->stats.asm_gemm_flops += 2.0 * h->np * (double)std::min(h->np, ((kprev + 16) / 16) * 16) * cnt[ASM_CNT_WIDE + 1];
+    {
+        double ksum = 0.0;                                // (bounds of the groups as asm_bins_b_k set them a round earlier)
+        for (int g = 0; g < ASM_NKG; ++g)
+          ksum += (double)cnt[ASM_CNT_WDONE + g] * (1 + (g == ASM_NKG - 1 ? kprev : std::min(kprev, asm_kgroup_bound_of(g, kref_prev, h->nu))));
+        h->stats.asm_gemm_flops += 2.0 * wide_cols * ksum;
+    }
     kprev = cnt[3];
     if (nrun == 0) break;
     h->stats.asm_rounds += 1;
@@ -1115,7 +1126,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     // populated last rounds of the active-set pass.
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)12e9;
-    long long cap = (long long)(0.25 * (double)free_b / (12.0 * np + 56.0 * np + n + 4.0 * o.asm_max_active + 64.0));
+    long long cap = (long long)(0.25 * (double)free_b / (12.0 * np + 88.0 * np + n + 4.0 * o.asm_max_active + 64.0));
     if (o.seg_max > 0) cap = std::min<long long>(cap, o.seg_max);
     cap = std::max<long long>(cap, S);
     cap = std::min<long long>(cap, 1 << 20);
@@ -1131,7 +1142,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->asm_pool = 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka); A_(h->H32, (size_t)np * np);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
-  A_(h->asm_lamw, G * np); A_(h->asm_xhw, G * np); A_(h->asm_wlist, G);
+  A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NLIST * G);
   A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 2 * G);
