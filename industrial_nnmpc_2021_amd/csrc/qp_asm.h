@@ -321,12 +321,12 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   else d.binlist[(size_t)(col - 1) * d.nseg + pos] = p;
 }
 
-// One problem: r_A = x_unc,A - b_A, S = H_AA as 16 x 16 fp64 tiles, blocked right-looking
-// Cholesky: diagonal tile + its inverse in the registers of wave 0 (rows on lanes, pivots by
-// v_readlane), TRSM and trailing updates on v_mfma_f64_16x16x4_f64 by all four waves, blocked
-// triangular solves by wave 0.  3 barriers per block column.
-// BIG = 0: one workgroup per entry of size-bin list `bin`, tiles in LDS sized for that bin.
+// Workgroup-per-problem variant (the first implementation; the solver uses it for the rare sets beyond 176
+// bounds, BIG = 1): r_A = x_unc,A - b_A, S = H_AA as 16 x 16 fp64 tiles, blocked right-looking Cholesky:
+// diagonal tile + its inverse by wave 0 (asm_diag16), TRSM and trailing updates on v_mfma_f64_16x16x4_f64 by
+// all four waves, blocked triangular solves by wave 0.  3 barriers per block column.
 // BIG = 1: persistent workgroups walk the big-set queue with the tiles in a global scratch slab (L2).
+// BIG = 0: one workgroup per entry of size-class list `bin`, tiles in LDS (kept for scripts/micro comparisons).
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double rdlane_d(double x, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
@@ -344,25 +344,6 @@ __device__ __forceinline__ f64x4_t tile_mma_nt(const double* A, const double* B,
 __device__ __forceinline__ double* asm_tile(double* T, int I, int J) { return T + ((size_t)I * (I + 1) / 2 + J) * ASM_TS; }
 
 #define ASM_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-// value of lane `L` of each 16-lane row, in every lane of that row (DPP row_newbcast: VALU only, the
-// result stays in VGPRs -- 120 live v_readlane SGPR pairs per tile made the compiler spill SGPRs)
-template <int L>
-__device__ __forceinline__ double bcast16_c(double x) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + L, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + L, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double bcast16(double x, int l) {   // l: compile-time constant after unrolling
-  switch (l) {
-    case 0: return bcast16_c<0>(x);   case 1: return bcast16_c<1>(x);   case 2: return bcast16_c<2>(x);
-    case 3: return bcast16_c<3>(x);   case 4: return bcast16_c<4>(x);   case 5: return bcast16_c<5>(x);
-    case 6: return bcast16_c<6>(x);   case 7: return bcast16_c<7>(x);   case 8: return bcast16_c<8>(x);
-    case 9: return bcast16_c<9>(x);   case 10: return bcast16_c<10>(x); case 11: return bcast16_c<11>(x);
-    case 12: return bcast16_c<12>(x); case 13: return bcast16_c<13>(x); case 14: return bcast16_c<14>(x);
-    default: return bcast16_c<15>(x);
-  }
-}
 
 template <class T> __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane);
 __device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane);
