@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dst, st.size())); CK(hipMemcpy(dst, st.data(), st.size(), hipMemcpyHostToDevice));
   CK(hipMalloc(&dstate, nseg * 4)); CK(hipMemset(dstate, 0, nseg * 4));
   int bin = max((m + 15) / 16, 4) - 4; if (bin >= ASM_NBIN) bin = ASM_NBIN - 1;
-  int cnt[ASM_NCNT] = {0}; cnt[4 + bin] = nseg; if (bin < ASM_NREG) cnt[ASM_CNT_F32 + bin] = nseg;
+  int cnt[ASM_NCNT] = {0}; cnt[4 + bin] = nseg; cnt[ASM_CNT_F32 + bin] = nseg;
   CK(hipMalloc(&dcnt, sizeof cnt)); CK(hipMemcpy(dcnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
   CK(hipMalloc(&dbin, (size_t)ASM_NLIST * nseg * 4));
   for (int b = 0; b < ASM_NLIST; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
@@ -68,12 +68,14 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS));
   CK(hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS));
   CK(hipFuncSetAttribute((const void*)asm_lambda_reg32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32_LDS));
+  CK(hipFuncSetAttribute((const void*)asm_lambda_reg32b_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32B_LDS));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
     if (variant == 0) hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nseg), dim3(256), lds_tile, 0, d, bin);
-    else if (variant == 2) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG32_LDS, 0, d);
+    else if (variant == 2 && bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG32_LDS, 0, d);
+    else if (variant == 2) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3((nseg + 3) / 4 + 2), dim3(256), ASM_REG32B_LDS, 0, d);
     else {
       if (bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, 0, d);
       else hipLaunchKernelGGL(asm_lambda_reg2_k, dim3((nseg + 1) / 2 + 2), dim3(128), ASM_REG2_LDS, 0, d);
