@@ -254,9 +254,9 @@ def main():
                               "the f32 rounds' XH32 = LAM32 Pinv32 on gemm_nt_f32_kdyn_k is in the same time and flop count)",
                     "bound": "mfma", "achieved": gach, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": gach / FP64_PEAK_TFLOPS,
-                    # mean HBM bytes per launch from the PMC passes of profiles/r01g_pmc_asm.json (B = 65536)
-                    "traffic": 1.77e9 if (args.workload == "cdu" and B == 65536) else None,
-                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01g_pmc_asm.json)",
+                    # mean HBM bytes per launch from the PMC passes of profiles/r01h_pmc_asm.json (B = 65536)
+                    "traffic": 7.9e8 if (args.workload == "cdu" and B == 65536) else None,
+                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01h_pmc_asm.json)",
                     "launches": st["asm_gemm_launches"], "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]),
                     "algorithmic_flops": "2 * (columns evaluated) * k_max per running problem and round (k_max = last active bound; columns = window past it) + one full-width pass 2 n k_max per problem",
                     "time_share": st["asm_gemm_ms"] / st["total_ms"]}
@@ -265,10 +265,10 @@ def main():
                              "wave per problem, tiles in the MFMA accumulators; f32 rounds until the set settles, then fp64)",
                    "bound": "mfma", "achieved": lach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": lach / FP64_PEAK_TFLOPS,
-                   # HBM bytes per launch from the PMC passes of profiles/r01g_pmc_asm.json (B = 65536): the gathered
+                   # HBM bytes per launch from the PMC passes of profiles/r01h_pmc_asm.json (B = 65536): the gathered
                    # Pinv blocks (algorithmic_GBps below) come from L2 / Infinity Cache, not from HBM
                    "traffic": 5.8e8 if (args.workload == "cdu" and B == 65536) else None,
-                   "traffic_unit": "HBM bytes per launch of the f32 kernel, 1.1e8 for the fp64 one (profiles/r01g_pmc_asm.json)",
+                   "traffic_unit": "HBM bytes per launch of the f32 kernel, 1.1e8 for the fp64 one (profiles/r01h_pmc_asm.json)",
                    "algorithmic_flops": "m^3/3 + 2 m^2 per problem and round, m = size of its active set (f32 and fp64 rounds "
                                         "alike; priced against the fp64 MFMA peak)",
                    "algorithmic_GBps": st["asm_lambda_bytes"] / (st["asm_lambda_ms"] * 1e-3) / 1e9,
