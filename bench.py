@@ -258,7 +258,7 @@ def main():
                     "traffic": 7.9e8 if (args.workload == "cdu" and B == 65536) else None,
                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01h_pmc_asm.json)",
                     "launches": st["asm_gemm_launches"], "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]),
-                    "algorithmic_flops": "2 * (columns evaluated) * k_max per running problem and round (k_max = last active bound; columns = window past it) + one full-width pass 2 n k_max per problem",
+                    "algorithmic_flops": "2 * (columns evaluated) * (own last active bound + 1) per running problem and round (columns = window past the round's last active bound) + x_unc = x0 Kunc' + one full-width pass per problem",
                     "time_share": st["asm_gemm_ms"] / st["total_ms"]}
             lach = st["asm_lambda_flops"] / (st["asm_lambda_ms"] * 1e-3) / 1e12
             lam = {"kernel": "asm_lambda_reg32_k + asm_lambda_reg_k (|A|x|A| Cholesky + solves of the multiplier systems: one "
