@@ -1070,7 +1070,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.asm_max_active <= 0) o.asm_max_active = 768;
   if (o.asm_max_active > 768) o.asm_max_active = 768;
   o.asm_max_active = std::max(16, (o.asm_max_active / 16) * 16);
-  if (o.asm_max_rounds <= 0) o.asm_max_rounds = 1000;
+  if (o.asm_max_rounds <= 0) o.asm_max_rounds = 200;
   if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
   if (o.refine_tol <= 0.0) o.refine_tol = 1e-10;
