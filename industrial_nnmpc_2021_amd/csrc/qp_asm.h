@@ -42,6 +42,8 @@ constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last
 constexpr int ASM_CNT_WIDEG = 24;  // counters[24 + g]: problems of k-group g awaiting the full-width check (their rows of
                                    // LAMW / XHW: region g, so that each region's GEMM stops at ITS last active bound),
 constexpr int ASM_CNT_WKMAX = 27;  // counters[27 + g]: that bound (from the group's definition; written by asm_bins_b_k),
+constexpr int ASM_TAIL_MB = 8;     // asm_tail_k keeps the tiles of sets of up to 128 bounds in LDS
+constexpr int ASM_CNT_TAIL = 35;   // counters[35]: problems handed to asm_tail_k
 constexpr int ASM_CNT_WDONE = 32;  // counters[32 + g]: problems of group g handled by the last asm_wide_k (statistics)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
@@ -150,13 +152,12 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
 }
 
 // Round stage 0a: ordered list of the active indices of every running problem and its length.
-__global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
-  __shared__ int wsum[4];
-  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (d.state[p] != ASM_RUN) return;
+// (one workgroup; returns the size of the set to all threads; wsum: 4 ints of LDS)
+__device__ __forceinline__ int asm_count_one(const AsmDev& d, int p, int hi_p, int* wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned char* st = d.st + (size_t)p * d.n;
   const bool words = (d.n & 3) == 0;                         // rows of st are then 4-byte aligned: 4 bounds per load
-  const int hi = min(d.n, d.hi[p]);                          // nothing is active at or beyond hi
+  const int hi = min(d.n, hi_p);                             // nothing is active at or beyond hi
   const int nw = words ? (hi + 3) >> 2 : hi;                 // items (dwords or bytes), a contiguous run per thread
   const int per = (nw + 255) / 256;
   const int j0 = min(nw, tid * per), j1 = min(nw, j0 + per);
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   }
   int inc = c;
   for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+  __syncthreads();                                           // wsum free again
   if (lane == 63) wsum[wave] = inc;
   __syncthreads();
   int base = inc - c;
@@ -192,6 +194,13 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
       for (int j = j0; j < j1; ++j) if (st[j]) idx[k++] = j;
     }
   }
+  return m;
+}
+__global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
+  __shared__ int wsum[4];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (d.state[p] != ASM_RUN) return;
+  const int m = asm_count_one(d, p, d.hi[p], wsum);
   if (tid == 0) {
     d.mg[p] = m;
     if (m <= d.max_active && d.work) {
@@ -348,26 +357,16 @@ __device__ __forceinline__ double* asm_tile(double* T, int I, int J) { return T 
 template <class T> __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane);
 __device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane);
 
-template <int BIG>
-__global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_bad;
+// One workgroup, one problem: rA <- lam = (H_AA)^-1 (x_unc,A - b_A) for the set idx[0..m).  rA [>= 16 ceil(m/16)]
+// and Yt [ASM_TS] in LDS, T: the lower 16 x 16 tiles (LDS or a global slab).  Returns 1 (to all threads) when H_AA
+// is not positive definite in fp64.  *s_bad: an int in LDS.
+__device__ __forceinline__ int asm_tile_solve(const AsmDev& d, int p, int m, const int* idx, double* rA, double* Yt, double* T,
+                                              int* s_bad) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cap = BIG ? d.max_active : asm_bin_cap(bin);  // rhs capacity of this variant
-  double* rA = sm;                                       // [cap]
-  double* Yt = rA + cap;                                 // inverse of the current diagonal tile
-  double* T = BIG ? d.scratch + (size_t)blockIdx.x * ((size_t)(cap / 16) * (cap / 16 + 1) / 2 * ASM_TS)
-                  : Yt + ASM_TS;                         // lower tiles
-  const int nitem = BIG ? d.counters[1] : d.counters[4 + bin];
-  const int* list = BIG ? d.biglist : d.binlist + (size_t)bin * d.nseg;
-  for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
-  const int p = list[it];
-  __syncthreads();                                       // previous queue item fully retired
-  if (tid == 0) s_bad = 0;
+  __syncthreads();                                       // previous use of the buffers fully retired
+  if (tid == 0) *s_bad = 0;
   const size_t o = (size_t)p * d.np;
   const unsigned char* st = d.st + (size_t)p * d.n;
-  const int* idx = d.idxg + (size_t)p * d.max_active;
-  const int m = d.mg[p];
   const int mb = (m + 15) / 16;
   __syncthreads();
   for (int i = tid; i < mb * 16; i += 256) {
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
     double* TKK = asm_tile(T, K, K);
     if (wave == 0) {
       const int bad = asm_diag16_call(TKK, Yt, lane);  // Y_K = L_KK^-1 -> Yt (L_KK itself is not needed again)
-      if (bad && lane == 0) s_bad = 1;
+      if (bad && lane == 0) *s_bad = 1;
     }
     __syncthreads();
     for (int I = K + 1 + wave; I < mb; I += 4) {       // TRSM: T(I,K) <- T(I,K) Y'
@@ -435,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
     }
     __syncthreads();
   }
-  if (s_bad) { if (tid == 0) d.state[p] = ASM_FALLBACK; continue; }
+  if (*s_bad) return 1;
   // ---- solves by wave 0:  L y = r (forward), L' lam = y (backward), 16-blocks
   if (wave == 0) {
     const int i = lane & 15, kq = lane >> 4;
@@ -475,11 +474,29 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
     }
   }
   __syncthreads();
-  {
-    if (tid == 0) d.prec[p] = 1;                               // an fp64 solve
+  return 0;
+}
+
+template <int BIG>
+__global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  const int cap = BIG ? d.max_active : asm_bin_cap(bin);  // rhs capacity of this variant
+  double* rA = sm;                                       // [cap]
+  double* Yt = rA + cap;                                 // inverse of the current diagonal tile
+  double* T = BIG ? d.scratch + (size_t)blockIdx.x * ((size_t)(cap / 16) * (cap / 16 + 1) / 2 * ASM_TS)
+                  : Yt + ASM_TS;                         // lower tiles
+  const int nitem = BIG ? d.counters[1] : d.counters[4 + bin];
+  const int* list = BIG ? d.biglist : d.binlist + (size_t)bin * d.nseg;
+  for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
+    const int p = list[it];
+    const int* idx = d.idxg + (size_t)p * d.max_active;
+    const int m = d.mg[p];
+    if (asm_tile_solve(d, p, m, idx, rA, Yt, T, &s_bad)) { if (tid == 0) d.state[p] = ASM_FALLBACK; continue; }
+    if (tid == 0) d.prec[p] = 1;                           // an fp64 solve
     double* lrow = d.lam + (size_t)d.row[p] * d.np;
-    for (int i = tid; i < m; i += 256) lrow[idx[i]] = rA[i];        // the rest of the row is zero (asm_update_k)
-  }
+    for (int i = tid; i < m; i += 256) lrow[idx[i]] = rA[i];   // the rest of the row is zero (asm_update_k)
   }
 }
 
@@ -1050,6 +1067,105 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
       d.hi[p] = d.n;                                                // ... anywhere
     }
   }
+}
+
+// ---- the tail: when only a few problems are still running, a round of eight launches and a host read-back is all
+// latency.  asm_tail_k finishes them on the device: one workgroup per problem loops count -> fp64 solve (tiles in its
+// L2 slab) -> x over ALL columns (n |A| MACs straight from Pinv) -> exchange rule, until the set settles or the budget
+// is spent.  Same arithmetic and the same certificate as the round kernels; u goes to the caller's buffer.
+__global__ __launch_bounds__(256) void asm_taillist_k(AsmDev d) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < d.nseg && d.state[p] == ASM_RUN) d.biglist[atomicAdd(&d.counters[ASM_CNT_TAIL], 1)] = p;   // a few hundred at most
+}
+__global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ int s_bad, wsum[4], s_i[4];
+  __shared__ double s_d[12];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= d.counters[ASM_CNT_TAIL]) return;
+  const int p = d.biglist[blockIdx.x];
+  double* rA = sm;                                           // [max_active] rhs -> lam
+  double* Yt = rA + d.max_active;
+  double* Tl = Yt + ASM_TS;                                  // tiles of sets of up to 16 ASM_TAIL_MB bounds (else: L2 slab)
+  unsigned char* dec = reinterpret_cast<unsigned char*>(Tl + ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS);   // [n] decisions
+  double* Tg = d.scratch + (size_t)blockIdx.x * ((size_t)(d.max_active / 16) * (d.max_active / 16 + 1) / 2 * ASM_TS);
+  const size_t o = (size_t)p * d.np;
+  unsigned char* st = d.st + (size_t)p * d.n;
+  const int* idx = d.idxg + (size_t)p * d.max_active;
+  int best = d.ninf_best[p], grace = d.alpha[p], hi = d.hi[p], rounds = d.rounds[p];
+  for (int it = 0; it < budget; ++it) {
+    const int m = asm_count_one(d, p, hi, wsum);
+    if (m > d.max_active) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
+    if (asm_tile_solve(d, p, m, idx, rA, Yt, m <= 16 * ASM_TAIL_MB ? Tl : Tg, &s_bad)) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
+    // x and the tests, decisions recorded (255: stays)
+    int ninf = 0, rmax = -1;
+    double l1 = 0.0, lmin = 1e300;
+    for (int r = tid; r < d.n; r += 256) {
+      const int sr = st[r];
+      const int k = r % d.nu;
+      const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
+      unsigned char dc = 255;
+      double x;
+      if (sr == 0) {
+        const double* Hr = d.H + (size_t)r * d.np;
+        double acc = 0.0;
+        for (int i = 0; i < m; ++i) acc += Hr[idx[i]] * rA[i];
+        x = d.xunc[o + r] - acc;
+        if (x > ub + d.bound_tol) dc = 1; else if (x < lb - d.bound_tol) dc = 2;
+      } else x = sr == 1 ? ub : lb;
+      d.u_out[(size_t)p * d.n + r] = x;                      // final once nothing changes
+      dec[r] = dc;
+      if (dc != 255) { ++ninf; rmax = max(rmax, r); }
+    }
+    __syncthreads();                                         // dec of the free variables complete
+    for (int i = tid; i < m; i += 256) {
+      const int a = idx[i], sa = st[a];
+      const double l = rA[i];
+      l1 += fabs(l); lmin = fmin(lmin, fabs(l));
+      if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { dec[a] = 0; ++ninf; rmax = max(rmax, a); }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      ninf += __shfl_xor(ninf, off); rmax = max(rmax, __shfl_xor(rmax, off));
+      l1 += __shfl_xor(l1, off); lmin = fmin(lmin, __shfl_xor(lmin, off));
+    }
+    __syncthreads();
+    if (lane == 0) { wsum[wave] = ninf; s_i[wave] = rmax; s_d[wave] = l1; s_d[4 + wave] = lmin; }
+    __syncthreads();
+    ninf = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    rmax = max(max(s_i[0], s_i[1]), max(s_i[2], s_i[3]));
+    ++rounds;
+    if (ninf == 0) {                                         // settled: certificate as in asm_update_k
+      double x1 = 0.0;
+      for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
+      for (int off = 32; off > 0; off >>= 1) x1 += __shfl_xor(x1, off);
+      if (lane == 0) s_d[8 + wave] = x1;
+      __syncthreads();
+      const double L1 = s_d[0] + s_d[1] + s_d[2] + s_d[3], X1 = s_d[8] + s_d[9] + s_d[10] + s_d[11];
+      const double LM = fmin(fmin(s_d[4], s_d[5]), fmin(s_d[6], s_d[7]));
+      const double QI = d.tqmax * X1;
+      const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
+      const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
+      if (!sure) for (int r = tid; r < d.n; r += 256) d.x[o + r] = d.u_out[(size_t)p * d.n + r];   // P itself has to confirm it
+      if (tid == 0) {
+        d.state[p] = sure ? ASM_CERT : ASM_DONE;
+        if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);
+        d.rounds[p] = rounds;
+      }
+      return;
+    }
+    // exchange rule (see asm_update_k)
+    int single = 0;
+    if (ninf < best) { best = ninf; grace = ASM_GRACE; }
+    else if (grace > 0) --grace;
+    else single = 1;
+    for (int r = tid; r < d.n; r += 256) {
+      const unsigned char dc = dec[r];
+      if (dc != 255 && (!single || r == rmax)) st[r] = dc;
+    }
+    hi = d.n;
+    __syncthreads();
+  }
+  if (tid == 0) { d.state[p] = ASM_FALLBACK; d.rounds[p] = rounds; }
 }
 
 // Independent fp64 certification with P itself (px = x P):  stationarity on the free set,

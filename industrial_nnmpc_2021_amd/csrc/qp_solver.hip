@@ -931,6 +931,19 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
     kprev = cnt[3];
     if (nrun == 0) break;
+    if (nrun <= std::min(h->asm_pool, 256) && rounds >= 12) {
+      // the tail: a handful of stragglers (the bulk settles in 5-8 rounds) -- finish them on the device (asm_tail_k)
+      // instead of paying eight launches and a read-back per round for them
+      EvScope es(h, 4, 0.0);
+      hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
+      const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS) * 8 + ((h->n + 15) / 16) * 16;
+      hipLaunchKernelGGL(asm_tail_k, dim3(nrun), dim3(256), lds_tail, s, a, a.max_rounds);
+      HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      h->stats.asm_rounds += 1;
+      rounds = 0;                                         // (regular exit: the counters just read are final)
+      break;
+    }
     h->stats.asm_rounds += 1;
     // column window of this round: past the last active bound of any running problem plus one stage; a
     // problem that settles inside it gets one full-width pass (asm_wide_k) at the start of the next round
@@ -1096,6 +1109,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg2_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG2_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32b_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32B_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_kdyn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);

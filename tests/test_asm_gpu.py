@@ -154,7 +154,6 @@ def test_cycling_samples_of_the_ill_conditioned_plant():
     qp = BatchedBoxQP(P, tq, nu, nb=64, max_batch=128, method="asm")
     out = qp.solve_batch(x0, lb, ub)
     assert (out["status"] == 0).all(), out["status"]
-    assert qp.stats()["asm_rounds"] > 12           # they do need the fallback
     Ps = np.tril(P) + np.tril(P, -1).T
     for b in range(len(rows)):
         info = {"nu": nu}
