@@ -124,7 +124,8 @@ int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double*
                          const double* ub, double* u, uint32_t* active, int32_t* status,
                          int32_t* iters, int32_t ptr_kind);
 
-/* Same, warm-started: guess (B x n bytes; 0 free, 1 at upper, 2 at lower bound; NULL = cold) is the
+/* Same, warm-started: guess (B x n bytes; 0 free, 1 at upper, 2 at lower bound; NULL = cold; a row whose first byte
+ * is 255 = no guess for that problem) is the
  * caller's estimate of the active set -- e.g. the previous step's set of a closed-loop chain shifted by
  * one stage (simulate_offline, lib/linearMPC.py:845-866, solves a slowly varying sequence of QPs).
  * The PDIP phase is skipped, the polish starts on the guess; the result is KKT-certified as always. */

@@ -1252,6 +1252,13 @@ __global__ void asm_gather_k(double* x0c, double* lbc, double* ubc, const double
     ubc[(size_t)i * nu + k] = ub[(size_t)p * nu + k];
   }
 }
+__global__ void asm_gather_guess_k(unsigned char* guess, const unsigned char* st, const int* state, const int* list, int cnt, int n) {
+  const int i = blockIdx.x;
+  if (i >= cnt) return;
+  const int p = list[i];
+  const bool settled = state[p] == ASM_DONE;                 // finished here, rejected by the check with P
+  for (int k = threadIdx.x; k < n; k += blockDim.x) guess[(size_t)i * n + k] = settled ? st[(size_t)p * n + k] : (unsigned char)255;
+}
 __global__ void asm_scatter_k(double* u, uint32_t* act, int* status, int* iters, const double* uc,
                               const uint32_t* actc, const int* stc, const int* itc, const int* list, int cnt,
                               int n, int words) {

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void refill_k(QpDev d) {
     d.r64[o + r] = 0.0; d.p64[o + r] = 0.0; d.v64[o + r] = 0.0;
   }
   qm = block_max(qm, shf);
-  const bool warm = d.guess_all != nullptr;
+  // (a guess row that starts with 255 means: no guess for this problem)
+  const bool warm = d.guess_all != nullptr && d.guess_all[(size_t)idx * d.n] != 255;
   if (warm) {
     // caller-supplied active set (e.g. the shifted set of the previous step of a closed-loop
     // chain): skip the PDIP, start the polish on it; the fp64 KKT check still certifies the result
@@ -1023,6 +1024,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   const int cntf = (int)fb.size();
   int* list = nullptr; double *x0c = nullptr, *lbc = nullptr, *ubc = nullptr, *uc = nullptr;
   uint32_t* actc = nullptr; int *stc = nullptr, *itc = nullptr;
+  unsigned char* guessc = nullptr;
+  HIPCHK(hipMalloc((void**)&guessc, (size_t)cntf * h->n));
   HIPCHK(hipMalloc((void**)&list, cntf * sizeof(int)));
   HIPCHK(hipMalloc((void**)&x0c, (size_t)cntf * h->n_aug * 8));
   HIPCHK(hipMalloc((void**)&lbc, (size_t)cntf * h->nu * 8));
@@ -1033,10 +1036,13 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   HIPCHK(hipMalloc((void**)&itc, (size_t)cntf * 8));
   HIPCHK(hipMemcpy(list, fb.data(), cntf * sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(asm_gather_k, dim3(cntf), dim3(128), 0, s, x0c, lbc, ubc, x0_dev, lb_dev, ub_dev, list, cntf, h->n_aug, h->nu);
+  // a problem whose set had settled but failed the check with P (inverse too inaccurate for its x) starts the polish
+  // on that set; the others (not settled, too large, not positive definite) run the PDIP from scratch
+  hipLaunchKernelGGL(asm_gather_guess_k, dim3(cntf), dim3(128), 0, s, guessc, h->asm_st, h->asm_state, list, cntf, h->n);
   int rc = 0;
   for (int b0 = 0; b0 < cntf && !rc; b0 += h->seg_max) {
     const int nb = std::min(h->seg_max, cntf - b0);
-    rc = solve_segment(h, nb, x0c + (size_t)b0 * h->n_aug, lbc + (size_t)b0 * h->nu, ubc + (size_t)b0 * h->nu, nullptr,
+    rc = solve_segment(h, nb, x0c + (size_t)b0 * h->n_aug, lbc + (size_t)b0 * h->nu, ubc + (size_t)b0 * h->nu, guessc + (size_t)b0 * h->n,
                        uc + (size_t)b0 * h->n, actc + (size_t)b0 * h->words, stc + b0, itc + 2 * (size_t)b0);
   }
   if (!rc) {
@@ -1044,7 +1050,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
                        list, cntf, h->n, h->words);
     HIPCHK(hipStreamSynchronize(s));
   }
-  hipFree(list); hipFree(x0c); hipFree(lbc); hipFree(ubc); hipFree(uc); hipFree(actc); hipFree(stc); hipFree(itc);
+  hipFree(guessc); hipFree(list); hipFree(x0c); hipFree(lbc); hipFree(ubc); hipFree(uc); hipFree(actc); hipFree(stc); hipFree(itc);
   h->stats.problems += nprob - cntf;   // solve_segment counted the fallback ones
   return rc;
 }
