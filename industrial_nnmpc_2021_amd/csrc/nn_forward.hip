@@ -25,35 +25,31 @@ using namespace nnmpc;
 namespace {
 
 // rows [0, Bp): pass 1 inputs, rows [Bp, 2Bp): pass 2 inputs; columns padded to ldk.
+// Workgroups walk the rows, threads the columns of a row (consecutive lanes read consecutive doubles).
 template <class T>
 __global__ void nn_assemble_k(T* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
                               int with_uprev, const double* __restrict__ x,
                               const double* __restrict__ uprev, const double* __restrict__ xs,
                               const double* __restrict__ us, const float* __restrict__ inv_scale) {
-  const int din = 2 * nx + (with_uprev ? 2 : 1) * nu;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)2 * Bp * ldk;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < total; i += stride) {
-    const int row = (int)(i / ldk), k = (int)(i % ldk);
+  const int o2 = nx + (with_uprev ? nu : 0);               // first column of the xs block
+  const int din = o2 + nx + nu;
+  for (int row = blockIdx.x; row < 2 * Bp; row += gridDim.x) {
     const int pass = row >= Bp, b = pass ? row - Bp : row;
-    float v = 0.f;
-    if (b < B && k < din) {
-      int kk = k;
-      if (kk < nx) {
-        v = (float)(pass ? xs[(size_t)b * nx + kk] : x[(size_t)b * nx + kk]) * inv_scale[kk];
-      } else {
-        kk -= nx;
-        if (with_uprev && kk < nu) {
-          v = (float)(pass ? us[(size_t)b * nu + kk] : uprev[(size_t)b * nu + kk]);
-        } else {
-          if (with_uprev) kk -= nu;
-          if (kk < nx) v = (float)xs[(size_t)b * nx + kk] * inv_scale[kk];
-          else v = (float)us[(size_t)b * nu + (kk - nx)];
-        }
+    const double* xa = (pass ? xs : x) + (size_t)b * nx;
+    const double* xb = xs + (size_t)b * nx;
+    const double* ua = with_uprev ? (pass ? us : uprev) + (size_t)b * nu : nullptr;
+    const double* ub = us + (size_t)b * nu;
+    T* dst = in + (size_t)row * ldk;
+    for (int k = threadIdx.x; k < ldk; k += blockDim.x) {
+      float f = 0.f;
+      if (b < B && k < din) {
+        if (k < nx) f = (float)xa[k] * inv_scale[k];
+        else if (k < o2) f = (float)ua[k - nx];
+        else if (k < o2 + nx) f = (float)xb[k - o2] * inv_scale[k - o2];
+        else f = (float)ub[k - o2 - nx];
       }
+      dst[k] = (T)f;
     }
-    in[i] = (T)v;
   }
 }
 
@@ -81,7 +77,8 @@ struct nnmpc_nn {
   std::vector<int> kpad;   // padded input width of layer l (multiple of 32)
   std::vector<int> npad;   // padded output width of layer l (multiple of 64)
   std::vector<float*> Wt;  // [npad][kpad] transposed weights (f32 path)
-  std::vector<bf16raw*> Wt16;  // same in bf16 (bf16 path)
+  std::vector<bf16raw*> Wt16;  // bf16 path: [n16][k16], k16 = layer input width rounded to 64 only (832 stays 832)
+  std::vector<int> k16, n16, ldc16;  // ldc16 = row length of the layer's output = k16 of the next layer
   int use_bf16;
   std::vector<float*> bias;  // [npad]
   int nx, nu, with_uprev, clip, max_batch;
@@ -117,11 +114,18 @@ void launch_layer(hipStream_t s, float* C, size_t ldc, const float* A, size_t ld
                      C, ldc, A, lda, Wt, ldb, K, bias);
 }
 template <int NB, bool RELU, bool BIAS, bool OUT16>
-void launch_layer16(hipStream_t s, void* C, size_t ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
-                    size_t ldb, int M, int N, int K, const float* bias) {
-  dim3 grid(N / NB, M / NB);
-  hipLaunchKernelGGL((gemm_nt_bf16_k<NB, RELU, BIAS, OUT16>), grid, dim3(256), TileCfg16<NB>::LDS_BYTES, s,
-                     C, ldc, A, lda, Wt, ldb, K, bias);
+void launch_layer16(hipStream_t s, void* C, int ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
+                    size_t ldb, int M, int K, const float* bias) {
+  const int ntm = M / NB, ntn = (ldc + NB - 1) / NB;
+  hipLaunchKernelGGL((gemm_nt_bf16_k<NB, RELU, BIAS, OUT16>), dim3(ntm * ntn), dim3(256), TileCfg16<NB>::LDS_BYTES, s,
+                     C, ldc, A, lda, Wt, ldb, K, bias, ntm, ntn);
+}
+template <bool RELU, bool BIAS>
+void launch_layer16_wide(hipStream_t s, __bf16* C, int ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
+                         size_t ldb, int M, int K, const float* bias) {
+  const int ntm = M / WBM, ntn = (ldc + WBN - 1) / WBN;
+  hipLaunchKernelGGL((gemm_nt_bf16_wide_k<RELU, BIAS>), dim3(ntm * ntn), dim3(512), W_LDS_BYTES, s,
+                     C, ldc, A, lda, Wt, ldb, K, bias, ntm, ntn);
 }
 }  // namespace
 
@@ -149,6 +153,7 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
   hipFuncSetAttribute((const void*)gemm_nt_bf16_k<128, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg16<128>::LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_nt_bf16_wide_k<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
   h->maxw = 0;
   int rc = 0;
   for (int l = 0; l < nlayers && !rc; ++l) {
@@ -171,12 +176,20 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
     hipMemcpy(db, bb.data(), bb.size() * 4, hipMemcpyHostToDevice);
     h->Wt.push_back(dw); h->bias.push_back(db);
     if (h->use_bf16) {
-      std::vector<bf16raw> w16(wt.size());
-      for (size_t e = 0; e < wt.size(); ++e) {   // round to nearest even
-        unsigned u; memcpy(&u, &wt[e], 4);
-        u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-        w16[e] = (bf16raw)u;
-      }
+      const bool lastl = l == nlayers - 1;
+      const int k16 = ((dims[l] + 63) / 64) * 64;
+      const int ldc = lastl ? 64 : ((dims[l + 1] + 63) / 64) * 64;
+      const int nb = (!lastl && ldc >= 2 * WBN) ? WBN : (dims[l + 1] > 64 ? 128 : 64);   // WBN: the wide-tile kernel
+      const int n16 = ((ldc + nb - 1) / nb) * nb;
+      h->k16.push_back(k16); h->n16.push_back(n16); h->ldc16.push_back(ldc);
+      std::vector<bf16raw> w16((size_t)(n16 + 64) * k16, 0);   // + 64 zero rows: the wide kernel's staging loads may run past the last tile
+      for (int i = 0; i < dims[l]; ++i)
+        for (int o = 0; o < dims[l + 1]; ++o) {   // round to nearest even
+          const float f = (float)W[l][(size_t)i * dims[l + 1] + o];
+          unsigned u; memcpy(&u, &f, 4);
+          u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+          w16[(size_t)o * k16 + i] = (bf16raw)u;
+        }
       bf16raw* d16 = nullptr;
       rc = nn_alloc(h, &d16, w16.size()); if (rc) break;
       hipMemcpy(d16, w16.data(), w16.size() * 2, hipMemcpyHostToDevice);
@@ -237,10 +250,10 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       dup = h->with_uprev ? uprev + (size_t)b0 * nu : nullptr; du = u + (size_t)b0 * nu;
     }
     if (h->use_bf16)
-      hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(2048), dim3(256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
+      hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(8192), dim3(256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
                          h->kpad[0], Bp, nb, nx, nu, h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     else
-      hipLaunchKernelGGL(nn_assemble_k<float>, dim3(2048), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
+      hipLaunchKernelGGL(nn_assemble_k<float>, dim3(8192), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
                          h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     hipEventRecord(h->e2, s);
     int cur = 0;
@@ -252,12 +265,15 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       const bool last = l == h->nlayers - 1;
       if (h->use_bf16) {
         const bf16raw* A16 = reinterpret_cast<const bf16raw*>(A);
-        if (N % 128 == 0) {
-          if (last) launch_layer16<128, false, false, false>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, nullptr);
-          else launch_layer16<128, true, true, true>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, h->bias[l]);
+        const int K16 = h->k16[l], ldc = h->ldc16[l];
+        if (!last && ldc >= 2 * WBN) {
+          launch_layer16_wide<true, true>(s, reinterpret_cast<__bf16*>(C), ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+        } else if (h->n16[l] % 128 == 0) {
+          if (last) launch_layer16<128, false, false, false>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
+          else launch_layer16<128, true, true, true>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
         } else {
-          if (last) launch_layer16<64, false, false, false>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, nullptr);
-          else launch_layer16<64, true, true, true>(s, C, N, A16, K, h->Wt16[l], K, M, N, K, h->bias[l]);
+          if (last) launch_layer16<64, false, false, false>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
+          else launch_layer16<64, true, true, true>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
         }
       } else if (N % 128 == 0) {
         if (last) launch_layer<128, false, false>(s, C, N, A, K, h->Wt[l], K, M, N, K, nullptr);

@@ -46,7 +46,7 @@ __device__ __forceinline__ void mma_chunk16(f32x16 (&acc)[TileCfg16<NB>::MT][Til
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int mj = 0; mj < MT; ++mj)
-        acc[mi][mj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][s], b[mj][s], acc[mi][mj], 0, 0, 0);
+        acc[mi][mj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[mj][s], a[mi][s], acc[mi][mj], 0, 0, 0);   // transposed block: lane = row of C
 }
 
 template <int NB>
@@ -67,18 +67,34 @@ __device__ __forceinline__ void store_chunk16(const f32x4 (&r)[TileCfg16<NB>::LD
   }
 }
 
-// C = act(A W' + bias); A [M][K] bf16, Wt [N][K] bf16; C bf16 (hidden layers) or f32 (head).
+// C = act(A W' + bias); A [M][K] bf16, Wt [ntn * NB][K] bf16 (rows beyond the layer's width are zero);
+// C bf16 (hidden layers) or f32 (head), only its first ldc columns exist (ldc a multiple of 4): the last
+// column tile may be partial, a wave whose columns all lie beyond ldc skips its MFMAs.
+// 1-D grid of ntm * ntn workgroups.  Workgroups go to the 8 XCDs round-robin by id, and each XCD has its own
+// L2: id -> (row panel, column tile) is chosen so that the ntn column tiles of one row panel run back to
+// back on ONE XCD -- the A panel comes from HBM once and from that L2 for the other ntn - 1 tiles.
+// The MFMAs compute the transposed 32 x 32 blocks (operands swapped): a lane then holds 4 CONSECUTIVE
+// columns of one row per register quad, so the epilogue stores 8 (bf16) / 16 (f32) bytes per lane.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
 template <int NB, bool RELU, bool BIAS, bool OUT_BF16>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, size_t ldc,
+__global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, int ldc,
                                                       const bf16raw* __restrict__ A, size_t lda,
                                                       const bf16raw* __restrict__ B, size_t ldb, int K,
-                                                      const float* __restrict__ bias) {
+                                                      const float* __restrict__ bias, int ntm, int ntn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(lds_raw);
   using Cf = TileCfg16<NB>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * NB, n0 = blockIdx.x * NB;
+  int tm, tn;
+  {
+    const int bid = blockIdx.x, full = (ntm >> 3) * 8 * ntn;
+    if (bid < full) { const int sq = bid >> 3; tm = (sq / ntn) * 8 + (bid & 7); tn = sq % ntn; }
+    else { const int rem = bid - full; tm = (ntm >> 3) * 8 + rem / ntn; tn = rem % ntn; }
+  }
+  const int m0 = tm * NB, n0 = tn * NB;
+  const bool live = n0 + wc * Cf::WT < ldc;                 // wave-uniform
   f32x16 acc[Cf::MT][Cf::MT];
 #pragma unroll
   for (int i = 0; i < Cf::MT; ++i)
@@ -102,22 +118,214 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, siz
       load_chunk16<NB>(ra, Ag + (kc + 1) * KC16, lda, tid);
       load_chunk16<NB>(rb, Bg + (kc + 1) * KC16, ldb, tid);
     }
-    mma_chunk16<NB>(acc, sA, sB, wr, wc, lane);
+    if (live) mma_chunk16<NB>(acc, sA, sB, wr, wc, lane);
   }
+  if (!live) return;
+  const int row0 = m0 + wr * Cf::WT + (lane & 31);
 #pragma unroll
-  for (int mi = 0; mi < Cf::MT; ++mi)
+  for (int mj = 0; mj < Cf::MT; ++mj)
 #pragma unroll
-    for (int mj = 0; mj < Cf::MT; ++mj)
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * Cf::WT + mj * 32 + 8 * j + 4 * (lane >> 5);
+      if (col < ldc) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * Cf::WT + mi * 32 + acc_row(r, lane);
-        const int col = n0 + wc * Cf::WT + mj * 32 + acc_col(lane);
-        float v = acc[mi][mj][r];
-        if (BIAS) v += bias[col];
-        if (RELU) v = v > 0.f ? v : 0.f;
-        if (OUT_BF16) reinterpret_cast<__bf16*>(Cv)[(size_t)row * ldc + col] = (__bf16)v;
-        else reinterpret_cast<float*>(Cv)[(size_t)row * ldc + col] = v;
+        for (int mi = 0; mi < Cf::MT; ++mi) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[mi][mj][4 * j + e] + bv[e];
+            v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
+          }
+          const size_t o = (size_t)(row0 + mi * 32) * ldc + col;
+          if (OUT_BF16) {
+            bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(Cv) + o) = h;
+          } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cv) + o) = v;
+          }
+        }
       }
+    }
+}
+
+
+// ---- wide-tile variant for the hidden layers: 256 rows x 208 columns per workgroup (832 = 4 x 208: the CDU
+// widths need no column padding), 512 threads = 8 waves as 4 (M) x 2 (N): a wave owns 64 rows x 7 (wn = 0) or
+// 6 (wn = 1) column tiles of v_mfma_f32_16x16x32_bf16 -- at most 112 accumulator registers, so two waves share a
+// SIMD (one workgroup per CU) and cover each other's LDS latency.
+// Why: the 128 x 128 kernel stages 32 KB per 2 MFLOP (64 flop/B: 39 TB/s of L2 reads at the bf16 peak) and has
+// 512 MFMA cycles per K-chunk to hide a global load; this tile stages 58 KB per 6.8 MFLOP (117 flop/B) and runs
+// ~1700 MFMA cycles per chunk and SIMD.
+// LDS image per operand and K-chunk of 64: [rows][64 bf16], 128-byte rows, 16-byte slot s of row r stored at
+// slot s ^ (r & 7): a wave's ds_read_b128 of one fragment (lane l: row l & 15, slot 4 ks + (l >> 4)) is
+// conflict-free in each of the instruction's four 16-lane groups, and so are the 8-lane groups of the
+// ds_write_b128 that fill it (8 lanes = the 8 slots of one row).
+// Operands swapped like above: a lane ends up with 4 consecutive columns of one row of C.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int WBM = 256, WBN = 208, WNT = 7;               // WNT: column tiles of the wn = 0 waves (wn = 1: 6)
+constexpr int W_STAGE = (WBM + 256) * 64;                  // bf16 elements per stage (A, then B padded to 256 rows: staging writes need no branch)
+constexpr int W_LDS_BYTES = 2 * W_STAGE * 2;               // two stages
+constexpr int W_BPIECES = WBN * 8;                         // 16-byte pieces of a B chunk
+
+template <bool RELU, bool BIAS>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ C, int ldc,
+                                                           const bf16raw* __restrict__ A, size_t lda,
+                                                           const bf16raw* __restrict__ B, size_t ldb, int K,
+                                                           const float* __restrict__ bias, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  bf16raw* lds = reinterpret_cast<bf16raw*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  int tm, tn;
+  {
+    const int bid = blockIdx.x, full = (ntm >> 3) * 8 * ntn;
+    if (bid < full) { const int sq = bid >> 3; tm = (sq / ntn) * 8 + (bid & 7); tn = sq % ntn; }
+    else { const int rem = bid - full; tm = (ntm >> 3) * 8 + rem / ntn; tn = rem % ntn; }
+  }
+  const int m0 = tm * WBM, n0 = tn * WBN;
+  f32x4 acc[4][WNT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging: piece f = tid + 512 i -> row f >> 3 = (tid >> 3) + 64 i, slot f & 7 = tid & 7.  Buffer loads: the
+  // per-thread byte offset is loop-invariant (one VGPR per operand), row block and K-chunk go into the scalar
+  // offset -- no vector address arithmetic in the loop (hipcc recomputes global_load addresses into the registers
+  // of the previous loads and guards that with vmcnt(0), which would drain the chunk in flight).  The B resource
+  // ends with the tile's 208 rows, so the 4th piece (rows 192..255) needs no branch: out of range reads 0.
+  const int prow = tid >> 3, pslot = tid & 7;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16raw*>(A + (size_t)m0 * lda), 0, (int)(WBM * lda * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16raw*>(B + (size_t)n0 * ldb), 0, (int)(WBN * ldb * 2), 0x00020000);
+  const int voA = (int)((prow * lda + pslot * 8) * 2), voB = (int)((prow * ldb + pslot * 8) * 2);
+  const int rsA = (int)(64 * lda * 2), rsB = (int)(64 * ldb * 2);   // bytes per block of 64 rows
+  const int soff = prow * 64 + ((pslot ^ (prow & 7)) * 8);  // + 64 rows * 64 per i
+  // Registers in flight: TWO sets for A (activations, streamed from HBM: the loads of chunk c + 2 are issued before
+  // the MFMAs of chunk c -- two chunk times, ~3500 cycles) and ONE for B (weights, L2 hits: loaded one chunk ahead,
+  // right after the previous chunk's registers went to LDS).  Two full sets would not fit 256 registers.
+  u32x4 ra0[4], ra1[4], rb[4];
+  auto gloadA = [&](u32x4 (&ra)[4], int kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, i * rsA + kc * 128, 0);
+  };
+  auto gloadB = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, voB, i * rsB + kc * 128, 0);
+  };
+  auto swrite = [&](const u32x4 (&ra)[4], bf16raw* sA) {
+    bf16raw* sB = sA + WBM * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sA + soff + 64 * 64 * i) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(sB + soff + 64 * 64 * i) = rb[i];   // rows 208..255: padding
+  };
+  const int lr = lane & 15, g = lane >> 4;
+  // One K-chunk: two steps of 32.  STAGE: the LDS writes of the next chunk's registers and the loads of the B chunk
+  // after it are issued BETWEEN the MFMAs of the second step (sched_group_barrier: 2 MFMAs, then one of them) --
+  // left to the end of the chunk, all 8 waves would write at once with the matrix pipes idle (58 KB at ~79 B/clk).
+  auto kstep = [&](const bf16raw* sA, const bf16raw* sB, int ks, auto&& stage) {
+    const int so = ((4 * ks + g) ^ (lr & 7)) * 8;
+    bf16x8 af[4], bf[WNT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(sA + 16 * mt * 64 + so);
+#pragma unroll
+    for (int nt = 0; nt < WNT; ++nt)
+      if (nt < WNT - 1 || wn == 0) bf[nt] = *reinterpret_cast<const bf16x8*>(sB + 16 * nt * 64 + so);
+#pragma unroll
+    for (int nt = 0; nt < WNT - 1; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+    stage();
+    if (wn == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        acc[mt][WNT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[WNT - 1], af[mt], acc[mt][WNT - 1], 0, 0, 0);
+    }
+  };
+  auto compute = [&](const bf16raw* st, auto&& stage) {
+    const bf16raw* sA = st + (64 * wm + lr) * 64;
+    const bf16raw* sB = st + WBM * 64 + (16 * WNT * wn + lr) * 64;
+    kstep(sA, sB, 0, [] {});
+    kstep(sA, sB, 1, stage);
+  };
+  const int nk = K / 64;
+  bf16raw* st0 = lds;
+  bf16raw* st1 = lds + W_STAGE;
+  // Loads and LDS writes are unconditional inside the loop (s_waitcnt counts are static: a conditional load would
+  // force vmcnt(0) before every LDS write).  A load of a chunk beyond K reads bytes of the next rows (the caller
+  // pads both buffers: see nnmpc_nn_create) or, past the resource, zeros; such a chunk is written to a stage that is
+  // never computed.  Order of the loads in flight at an LDS write of chunk c + 1: A(c + 1), B(c + 1), A(c + 2).
+  gloadA(ra0, 0);
+  gloadB(0);
+  gloadA(ra1, 1);
+  swrite(ra0, st0);
+  gloadB(1);
+  __syncthreads();
+  auto interleave = [] {
+    // 24 MFMAs of the step are in this scheduling region: (2 MFMA, 1 LDS write) x 8, (2 MFMA, 1 buffer load) x 4
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+  };
+  int kc = 0;
+  for (; kc + 1 < nk; kc += 2) {
+    gloadA(ra0, kc + 2);
+    compute(st0, [&] { swrite(ra1, st1); gloadB(kc + 2); interleave(); });
+    __syncthreads();
+    gloadA(ra1, kc + 3);
+    compute(st1, [&] { swrite(ra0, st0); gloadB(kc + 3); interleave(); });
+    __syncthreads();
+  }
+  if (kc < nk) compute(st0, [] {});                        // odd number of chunks: the last one is in stage 0
+  // ---- epilogue.  Straight from the accumulators a store instruction would write 16 rows x 32 bytes (a quarter of
+  // a cache line per row); instead every wave transposes its own 64 x 112 block through a private LDS region (the
+  // stages are free after the last barrier; no workgroup barrier needed: DS operations of a wave run in order) and
+  // stores 16-byte pieces of whole rows (224 contiguous bytes per row).  Row stride 240 B: 2-way conflicts on the
+  // 8-byte writes, 16-byte aligned reads.
+  constexpr int ESTRIDE = 240;
+  __syncthreads();                                         // an odd last chunk is still being read from stage 0
+  unsigned char* er = lds_raw + wave * (64 * ESTRIDE);
+#pragma unroll
+  for (int nt = 0; nt < WNT; ++nt) {
+    if (nt < WNT - 1 || wn == 0) {
+      const int col = n0 + 16 * (WNT * wn + nt) + 4 * g;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (BIAS && col < ldc) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = acc[mt][nt][e] + bv[e];
+          v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
+        }
+        const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(er + (16 * mt + lr) * ESTRIDE + 32 * nt + 8 * g) = h;
+      }
+    }
+  }
+  const int npc = wn ? 2 * (WNT - 1) : 2 * WNT;             // 16-byte pieces per row of this wave's block
+  __bf16* Cw = C + (size_t)(m0 + 64 * wm) * ldc + n0 + 16 * WNT * wn;
+#pragma unroll
+  for (int i = 0; i < 2 * WNT; ++i) {
+    const int q = lane + 64 * i;
+    if (q < 64 * npc) {
+      const int row = q / npc, c = q - row * npc;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(er + row * ESTRIDE + 16 * c);
+      if (n0 + 16 * WNT * wn + 8 * c < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)row * ldc + 8 * c) = v;
+    }
+  }
 }
 
 }  // namespace nnmpc
