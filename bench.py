@@ -80,16 +80,16 @@ def bench_nn(args, torch, dev, rank, world, dist):
     res = {}
     for mode in ("f32", "bf16"):
         net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu),
-                           max_batch=65536, use_bf16=(mode == "bf16"))
+                           max_batch=262144, use_bf16=(mode == "bf16"))
         for _ in range(args.warmup):
             net.forward_device(B, x, None, xs, us, u)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        t0 = time.perf_counter(); gm = 0.0
+        t0 = time.perf_counter(); gm = 0.0; dm = 0.0
         for _ in range(args.steps):
             net.forward_device(B, x, None, xs, us, u)
-            gm += net.last_ms()[0]
+            gm += net.last_ms()[0]; dm += net.last_ms()[1]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -101,7 +101,8 @@ def bench_nn(args, torch, dev, rank, world, dist):
                                 -np.ones(nu), np.ones(nu), False)
         err = float(np.abs(u[:k].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()))
         res[mode] = dict(states_per_s=world * B * args.steps / dt, ms_per_step=1e3 * dt / args.steps,
-                         gemm_TFLOPs=flops_per_state * B * args.steps / (gm * 1e-3) / 1e12, max_rel_err_vs_fp64_oracle=err)
+                         gemm_TFLOPs=flops_per_state * B * args.steps / (gm * 1e-3) / 1e12, max_rel_err_vs_fp64_oracle=err,
+                         device_ms_per_step=dm / args.steps, gemm_ms_per_step=gm / args.steps)
         net.close()
     if rank == 0:
         f = res["f32"]

@@ -88,7 +88,8 @@ struct nnmpc_nn {
   int maxw;
   double *sx, *suprev, *sxs, *sus, *su;  // staging for host pointers
   hipStream_t stream;
-  hipEvent_t e0, e1, e2, e3;
+  hipEvent_t e0, e1;
+  std::vector<hipEvent_t> eg;   // (start, end) of the GEMMs of every sub-batch of a call
   double gemm_ms, total_ms;
   std::vector<void*> allocs;
 };
@@ -123,9 +124,15 @@ void launch_layer16(hipStream_t s, void* C, int ldc, const bf16raw* A, size_t ld
 template <bool RELU, bool BIAS>
 void launch_layer16_wide(hipStream_t s, __bf16* C, int ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
                          size_t ldb, int M, int K, const float* bias) {
-  const int ntm = M / WBM, ntn = (ldc + WBN - 1) / WBN;
-  hipLaunchKernelGGL((gemm_nt_bf16_wide_k<RELU, BIAS>), dim3(ntm * ntn), dim3(512), W_LDS_BYTES, s,
-                     C, ldc, A, lda, Wt, ldb, K, bias, ntm, ntn);
+  const int ntn = (ldc + WBN - 1) / WBN;
+  const int npg = std::max(1, 32 / ntn);                    // panel groups per XCD: 8 * npg * ntn workgroups <= 256 CUs
+  // the kernel addresses A with 32-bit byte offsets: slices of less than 2^31 bytes
+  const int max_rows = (int)(((size_t)1 << 31) / (lda * 2) / WBM) * WBM - WBM;
+  for (int m = 0; m < M; m += max_rows) {
+    const int rows = std::min(max_rows, M - m), ntm = rows / WBM;
+    hipLaunchKernelGGL((gemm_nt_bf16_wide_k<RELU, BIAS>), dim3(8 * npg * ntn), dim3(512), W_LDS_BYTES, s,
+                       C + (size_t)m * ldc, ldc, A + (size_t)m * lda, lda, Wt, ldb, K, bias, ntm, ntn, npg);
+  }
 }
 }  // namespace
 
@@ -149,7 +156,7 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   h->gemm_ms = h->total_ms = 0;
   h->dims.assign(dims, dims + nlayers + 1);
   hipStreamCreate(&h->stream);
-  hipEventCreate(&h->e0); hipEventCreate(&h->e1); hipEventCreate(&h->e2); hipEventCreate(&h->e3);
+  hipEventCreate(&h->e0); hipEventCreate(&h->e1);
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
   hipFuncSetAttribute((const void*)gemm_nt_bf16_k<128, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg16<128>::LDS_BYTES);
@@ -220,7 +227,8 @@ int nnmpc_nn_destroy(nnmpc_nn* h) {
   if (!h) return NNMPC_OK;
   hipDeviceSynchronize();
   for (void* p : h->allocs) hipFree(p);
-  hipEventDestroy(h->e0); hipEventDestroy(h->e1); hipEventDestroy(h->e2); hipEventDestroy(h->e3);
+  hipEventDestroy(h->e0); hipEventDestroy(h->e1);
+  for (hipEvent_t e : h->eg) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return NNMPC_OK;
@@ -235,7 +243,9 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
   const int nx = h->nx, nu = h->nu, MB = h->max_batch;
   double gemm_ms = 0.0;
   hipEventRecord(h->e0, s);
-  for (int b0 = 0; b0 < B; b0 += MB) {
+  size_t nsub = 0;
+  for (int b0 = 0; b0 < B; b0 += MB, ++nsub) {
+    while (h->eg.size() < 2 * (nsub + 1)) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->eg.push_back(e); }
     const int nb = std::min(MB, B - b0);
     const int Bp = ((nb + 127) / 128) * 128;
     const double *dx, *dup, *dxs, *dus; double* du;
@@ -255,7 +265,7 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
     else
       hipLaunchKernelGGL(nn_assemble_k<float>, dim3(8192), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
                          h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
-    hipEventRecord(h->e2, s);
+    hipEventRecord(h->eg[2 * nsub], s);
     int cur = 0;
     const int M = 2 * Bp;
     for (int l = 0; l < h->nlayers; ++l) {
@@ -284,20 +294,20 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       }
       cur ^= 1;
     }
-    hipEventRecord(h->e3, s);
+    hipEventRecord(h->eg[2 * nsub + 1], s);
     hipLaunchKernelGGL(nn_combine_k, dim3(1024), dim3(256), 0, s, du, h->act[cur], h->npad[h->nlayers - 1], Bp,
                        nb, nu, dus, h->ulb, h->uub, h->clip);
-    if (ptr_kind == NNMPC_HOST) HIPCHK(hipMemcpyAsync(u + (size_t)b0 * nu, h->su, (size_t)nb * nu * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, h->e2, h->e3);
-    gemm_ms += ms;
+    if (ptr_kind == NNMPC_HOST) {                           // the staging buffers are reused by the next sub-batch
+      HIPCHK(hipMemcpyAsync(u + (size_t)b0 * nu, h->su, (size_t)nb * nu * 8, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
   }
   hipEventRecord(h->e1, s);
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   float tot = 0.f;
   hipEventElapsedTime(&tot, h->e0, h->e1);
+  for (size_t i = 0; i < nsub; ++i) { float ms = 0.f; hipEventElapsedTime(&ms, h->eg[2 * i], h->eg[2 * i + 1]); gemm_ms += ms; }
   h->gemm_ms = gemm_ms; h->total_ms = tot;
   return NNMPC_OK;
 }

@@ -166,25 +166,32 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, int
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WBM = 256, WBN = 208, WNT = 7;               // WNT: column tiles of the wn = 0 waves (wn = 1: 6)
 constexpr int W_STAGE = (WBM + 256) * 64;                  // bf16 elements per stage (A, then B padded to 256 rows: staging writes need no branch)
-constexpr int W_LDS_BYTES = 2 * W_STAGE * 2;               // two stages
+constexpr int W_LDS_BYTES = 2 * W_STAGE * 2 + 1024;        // two stages + the workgroup's bias values
 constexpr int W_BPIECES = WBN * 8;                         // 16-byte pieces of a B chunk
 
 template <bool RELU, bool BIAS>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ C, int ldc,
                                                            const bf16raw* __restrict__ A, size_t lda,
                                                            const bf16raw* __restrict__ B, size_t ldb, int K,
-                                                           const float* __restrict__ bias, int ntm, int ntn) {
+                                                           const float* __restrict__ bias, int ntm, int ntn, int npg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(lds_raw);
+  float* sbias = reinterpret_cast<float*>(lds_raw + 2 * W_STAGE * 2);   // this workgroup's 208 bias values
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;
-  int tm, tn;
-  {
-    const int bid = blockIdx.x, full = (ntm >> 3) * 8 * ntn;
-    if (bid < full) { const int sq = bid >> 3; tm = (sq / ntn) * 8 + (bid & 7); tn = sq % ntn; }
-    else { const int rem = bid - full; tm = (ntm >> 3) * 8 + rem / ntn; tn = rem % ntn; }
-  }
-  const int m0 = tm * WBM, n0 = tn * WBN;
+  // Persistent workgroups (grid = 8 XCDs x npg panel groups x ntn column tiles, at most one per CU): workgroup w keeps
+  // ONE column tile (its 208 weight rows stay L2-hot, its bias sits in LDS) and walks row panels
+  //   p = (w & 7) + 8 q + 8 npg it,   q = (w >> 3) / ntn,   it = 0, 1, ...
+  // The K-chunks of all its panels form ONE software pipeline: the first chunks of the next panel are loaded while
+  // the last chunks of this one are multiplied and its result is stored (a workgroup per tile spent a quarter of its
+  // time filling and draining the pipeline).  Workgroups go to the XCDs round-robin by id, so the ntn workgroups that
+  // share a panel run on the SAME XCD at the same time: the panel comes from HBM once, then from that L2.
+  const int wq = (int)blockIdx.x >> 3, tn = wq % ntn;
+  const int p0 = ((int)blockIdx.x & 7) + 8 * (wq / ntn), pstride = 8 * npg;
+  if (p0 >= ntm) return;
+  const int np = (ntm - p0 + pstride - 1) / pstride;        // panels of this workgroup
+  const int n0 = tn * WBN;
+  if (tid < WBN) sbias[tid] = (BIAS && n0 + tid < ldc) ? bias[n0 + tid] : 0.f;
   f32x4 acc[4][WNT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -193,13 +200,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
   // staging: piece f = tid + 512 i -> row f >> 3 = (tid >> 3) + 64 i, slot f & 7 = tid & 7.  Buffer loads: the
   // per-thread byte offset is loop-invariant (one VGPR per operand), row block and K-chunk go into the scalar
   // offset -- no vector address arithmetic in the loop (hipcc recomputes global_load addresses into the registers
-  // of the previous loads and guards that with vmcnt(0), which would drain the chunk in flight).  The B resource
-  // ends with the tile's 208 rows, so the 4th piece (rows 192..255) needs no branch: out of range reads 0.
+  // of the previous loads and guards that with vmcnt(0), which would drain the chunk in flight).  The 4th B piece
+  // (rows 192..255 of a 208-row tile) is loaded without a branch: it reads the next tile's rows, or the 64 zero rows
+  // the caller appends to the weights (nnmpc_nn_create), and lands in the padding rows of the stage.
   const int prow = tid >> 3, pslot = tid & 7;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16raw*>(A + (size_t)m0 * lda), 0, (int)(WBM * lda * 2), 0x00020000);
+      const_cast<bf16raw*>(A), 0, (int)((size_t)ntm * WBM * lda * 2), 0x00020000);   // the caller keeps this below 2^31
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16raw*>(B + (size_t)n0 * ldb), 0, (int)(WBN * ldb * 2), 0x00020000);
+      const_cast<bf16raw*>(B), 0, (int)((size_t)ntn * WBN * ldb * 2), 0x00020000);
   const int voA = (int)((prow * lda + pslot * 8) * 2), voB = (int)((prow * ldb + pslot * 8) * 2);
   const int rsA = (int)(64 * lda * 2), rsB = (int)(64 * ldb * 2);   // bytes per block of 64 rows
   const int soff = prow * 64 + ((pslot ^ (prow & 7)) * 8);  // + 64 rows * 64 per i
@@ -207,13 +215,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
   // the MFMAs of chunk c -- two chunk times, ~3500 cycles) and ONE for B (weights, L2 hits: loaded one chunk ahead,
   // right after the previous chunk's registers went to LDS).  Two full sets would not fit 256 registers.
   u32x4 ra0[4], ra1[4], rb[4];
-  auto gloadA = [&](u32x4 (&ra)[4], int kc) {
+  auto gloadA = [&](u32x4 (&ra)[4], int off) {               // off: byte offset of (panel, chunk)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, i * rsA + kc * 128, 0);
+    for (int i = 0; i < 4; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, i * rsA + off, 0);
   };
-  auto gloadB = [&](int kc) {
+  auto gloadB = [&](int off) {                              // off: byte offset of (tile, chunk)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, voB, i * rsB + kc * 128, 0);
+    for (int i = 0; i < 4; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, voB, i * rsB + off, 0);
   };
   auto swrite = [&](const u32x4 (&ra)[4], bf16raw* sA) {
     bf16raw* sB = sA + WBM * 64;
@@ -256,15 +264,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
   bf16raw* st0 = lds;
   bf16raw* st1 = lds + W_STAGE;
   // Loads and LDS writes are unconditional inside the loop (s_waitcnt counts are static: a conditional load would
-  // force vmcnt(0) before every LDS write).  A load of a chunk beyond K reads bytes of the next rows (the caller
-  // pads both buffers: see nnmpc_nn_create) or, past the resource, zeros; such a chunk is written to a stage that is
-  // never computed.  Order of the loads in flight at an LDS write of chunk c + 1: A(c + 1), B(c + 1), A(c + 2).
-  gloadA(ra0, 0);
-  gloadB(0);
-  gloadA(ra1, 1);
-  swrite(ra0, st0);
-  gloadB(1);
-  __syncthreads();
+  // force vmcnt(0) before every LDS write).  Past the last step the load cursors wrap (A) / stay on the last tile
+  // (B): valid bytes, written to a stage that is never computed.  Order of the loads in flight at an LDS write of
+  // step s + 1: A(s + 1), B(s + 1), A(s + 2).
+  const int S = np * nk;                                    // steps = panels x chunks
+  const int panelA = (int)(WBM * lda * 2), offB = tn * (int)(WBN * ldb * 2);
+  int ca = 0, pa = 0, oa = p0 * panelA, cb = 0;             // load cursors: chunk / panel / panel byte offset of the next A load; chunk of the next B load
+  auto nextA = [&](u32x4 (&ra)[4]) {
+    gloadA(ra, oa + ca * 128);
+    if (++ca == nk) { ca = 0; if (pa + 1 < np) { ++pa; oa += pstride * panelA; } }
+  };
+  auto nextB = [&] {
+    gloadB(offB + cb * 128);
+    if (++cb == nk) cb = 0;
+  };
   auto interleave = [] {
     // 24 MFMAs of the step are in this scheduling region: (2 MFMA, 1 LDS write) x 8, (2 MFMA, 1 buffer load) x 4
 #pragma unroll
@@ -278,53 +291,76 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
   };
-  int kc = 0;
-  for (; kc + 1 < nk; kc += 2) {
-    gloadA(ra0, kc + 2);
-    compute(st0, [&] { swrite(ra1, st1); gloadB(kc + 2); interleave(); });
-    __syncthreads();
-    gloadA(ra1, kc + 3);
-    compute(st1, [&] { swrite(ra0, st0); gloadB(kc + 3); interleave(); });
-    __syncthreads();
-  }
-  if (kc < nk) compute(st0, [] {});                        // odd number of chunks: the last one is in stage 0
-  // ---- epilogue.  Straight from the accumulators a store instruction would write 16 rows x 32 bytes (a quarter of
-  // a cache line per row); instead every wave transposes its own 64 x 112 block through a private LDS region (the
-  // stages are free after the last barrier; no workgroup barrier needed: DS operations of a wave run in order) and
-  // stores 16-byte pieces of whole rows (224 contiguous bytes per row).  Row stride 240 B: 2-way conflicts on the
-  // 8-byte writes, 16-byte aligned reads.
+  // ---- end of a tile.  Straight from the accumulators a store instruction would write 16 rows x 32 bytes (a quarter
+  // of a cache line per row); instead every wave transposes its own 64 x 112 block, 32 rows at a time, through a
+  // private region of the stage that was just multiplied (free: the barrier of the step is behind us; the OTHER stage
+  // already holds the next tile's first chunk) and stores 16-byte pieces of whole rows (224 contiguous bytes per row).
+  // DS operations of a wave run in order, so only the hand-back of the stage needs a workgroup barrier.
+  // Row stride 240 B: 2-way conflicts on the 8-byte writes, 16-byte aligned reads.
   constexpr int ESTRIDE = 240;
-  __syncthreads();                                         // an odd last chunk is still being read from stage 0
-  unsigned char* er = lds_raw + wave * (64 * ESTRIDE);
+  const int npc = wn ? 2 * (WNT - 1) : 2 * WNT;             // 16-byte pieces per row of this wave's block
+  auto epilogue = [&](int pc, bf16raw* stage) {
+    unsigned char* er = reinterpret_cast<unsigned char*>(stage) + wave * (32 * ESTRIDE);
+    const int m0 = (p0 + pstride * pc) * WBM;
+    __bf16* Cw = C + (size_t)(m0 + 64 * wm) * ldc + n0 + 16 * WNT * wn;
 #pragma unroll
-  for (int nt = 0; nt < WNT; ++nt) {
-    if (nt < WNT - 1 || wn == 0) {
-      const int col = n0 + 16 * (WNT * wn + nt) + 4 * g;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (BIAS && col < ldc) bv = *reinterpret_cast<const f32x4*>(bias + col);
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        float v[4];
+      for (int nt = 0; nt < WNT; ++nt) {
+        if (nt < WNT - 1 || wn == 0) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + 16 * (WNT * wn + nt) + 4 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = acc[mt][nt][e] + bv[e];
-          v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
+          for (int m2 = 0; m2 < 2; ++m2) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[2 * h + m2][nt][e] + bv[e];
+              v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
+              acc[2 * h + m2][nt][e] = 0.f;
+            }
+            const bf16x4 hv = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(er + (16 * m2 + lr) * ESTRIDE + 32 * nt + 8 * g) = hv;
+          }
         }
-        const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *reinterpret_cast<bf16x4*>(er + (16 * mt + lr) * ESTRIDE + 32 * nt + 8 * g) = h;
+      }
+      int row = lane / npc, c = lane - row * npc;            // piece q = lane + 64 i -> (row, c) = (q / npc, q % npc)
+#pragma unroll 1
+      for (int i = 0; i < WNT; ++i) {                        // rolled: the registers belong to the loads in flight
+        if (row < 32) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(er + row * ESTRIDE + 16 * c);
+          if (n0 + 16 * WNT * wn + 8 * c < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)(32 * h + row) * ldc + 8 * c) = v;
+        }
+        c += 64 % npc; row += 64 / npc;
+        if (c >= npc) { c -= npc; ++row; }
       }
     }
+    __syncthreads();                                        // the stage goes back to the pipeline
+  };
+  int cs = 0, pcur = 0;                                     // chunk / panel (of this workgroup) being multiplied
+  auto endstep = [&](bf16raw* stage) {
+    if (++cs == nk) { epilogue(pcur, stage); cs = 0; ++pcur; }
+  };
+  nextA(ra0);
+  nextB();
+  nextA(ra1);
+  swrite(ra0, st0);
+  nextB();
+  __syncthreads();
+  int sp = 0;
+  for (; sp + 1 < S; sp += 2) {
+    nextA(ra0);
+    compute(st0, [&] { swrite(ra1, st1); nextB(); interleave(); });
+    __syncthreads();
+    endstep(st0);
+    nextA(ra1);
+    compute(st1, [&] { swrite(ra0, st0); nextB(); interleave(); });
+    __syncthreads();
+    endstep(st1);
   }
-  const int npc = wn ? 2 * (WNT - 1) : 2 * WNT;             // 16-byte pieces per row of this wave's block
-  __bf16* Cw = C + (size_t)(m0 + 64 * wm) * ldc + n0 + 16 * WNT * wn;
-#pragma unroll
-  for (int i = 0; i < 2 * WNT; ++i) {
-    const int q = lane + 64 * i;
-    if (q < 64 * npc) {
-      const int row = q / npc, c = q - row * npc;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(er + row * ESTRIDE + 16 * c);
-      if (n0 + 16 * WNT * wn + 8 * c < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)row * ldc + 8 * c) = v;
-    }
+  if (sp < S) {                                             // odd number of steps: the last one is in stage 0
+    compute(st0, [] {});
+    __syncthreads();
+    endstep(st0);
   }
 }
 
