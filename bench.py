@@ -84,17 +84,17 @@ def bench_nn(args, torch, dev, rank, world, dist):
         for _ in range(args.warmup):
             net.forward_device(B, x, None, xs, us, u)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         t0 = time.perf_counter(); gm = 0.0; dm = 0.0
         for _ in range(args.steps):
             net.forward_device(B, x, None, xs, us, u)
             gm += net.last_ms()[0]; dm += net.last_ms()[1]
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         k = 512
         ref = onn.control_input(W, x[:k].cpu().numpy(), None, xs[:k].cpu().numpy(), us[:k].cpu().numpy(), xscale,
@@ -116,7 +116,7 @@ def bench_nn(args, torch, dev, rank, world, dist):
                "parity": {"max_rel_err_vs_fp64_oracle": f["max_rel_err_vs_fp64_oracle"]},
                "bf16": dict(res["bf16"], peak_TFLOPs=2500.0, frac=res["bf16"]["gemm_TFLOPs"] / 2500.0)}
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
 
@@ -148,9 +148,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # NNMPC_FORCE_DIST=1: run the process-group code (RCCL init, gather, max-reduce) with a single rank too
+    use_dist = world > 1 or os.environ.get("NNMPC_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload == "nn":
@@ -183,12 +186,12 @@ def main():
     def step():
         qp.solve_batch_device(B, x0, lb, ub, u, act, status, iters)
         first = (u[:, :nu] + us).contiguous()      # get_control_sequence adds us back (:689); ut = useq[0:Nu] (:856)
-        if world > 1:
+        if dist is not None:
             dist.gather(first, gathered, dst=0)     # the single RCCL gather over xGMI
         return first
 
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,7 +205,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -328,7 +331,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, x0_h, lb_h, ub_h,
                                                budget_s=20.0 if args.workload == "cdu" else 10.0, workload=args.workload)
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

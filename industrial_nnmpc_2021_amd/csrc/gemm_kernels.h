@@ -17,7 +17,16 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_k(float* __restrict__ C, size
   using Cf = TileCfg<NB>;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * NB, n0 = blockIdx.x * NB;
+  // Workgroups go to the 8 XCDs (each with its own L2) round-robin by linear id: remap id -> tile so that the
+  // gridDim.x column tiles of one row panel run back to back on ONE XCD (the A panel then comes from HBM once and
+  // from that L2 for the other tiles).  A bijection of the grid; the tail (gridDim.y % 8 panels) keeps the plain order.
+  int tm, tn;
+  {
+    const int ntn = gridDim.x, ntm = gridDim.y, bid = blockIdx.x + ntn * blockIdx.y, full = (ntm >> 3) * 8 * ntn;
+    if (bid < full) { const int sq = bid >> 3; tm = (sq / ntn) * 8 + (bid & 7); tn = sq % ntn; }
+    else { const int rem = bid - full; tm = (ntm >> 3) * 8 + rem / ntn; tn = rem % ntn; }
+  }
+  const int m0 = tm * NB, n0 = tn * NB;
   f32x16 acc[Cf::MT][Cf::MT];
   zero_acc<NB>(acc);
   PlainOp a{A + (size_t)m0 * lda, lda};

@@ -260,10 +260,10 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       dup = h->with_uprev ? uprev + (size_t)b0 * nu : nullptr; du = u + (size_t)b0 * nu;
     }
     if (h->use_bf16)
-      hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(8192), dim3(256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
+      hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(8192), dim3(h->kpad[0] % 192 == 0 ? 192 : 256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
                          h->kpad[0], Bp, nb, nx, nu, h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     else
-      hipLaunchKernelGGL(nn_assemble_k<float>, dim3(8192), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
+      hipLaunchKernelGGL(nn_assemble_k<float>, dim3(8192), dim3(h->kpad[0] % 192 == 0 ? 192 : 256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
                          h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     hipEventRecord(h->eg[2 * nsub], s);
     int cur = 0;

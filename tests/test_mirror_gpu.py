@@ -145,6 +145,55 @@ def test_nn_bf16_path_tolerance():
     assert np.abs(u[0] - us[0]).max() < 1e-12       # steady-state row: both passes identical -> exact
 
 
+def _bf16(a):
+    """Round to nearest-even bf16 (returned as float32), like v_cvt_pk_bf16_f32 / the library's weight upload."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _bf16_forward(W, x, uprev, xs, us, xscale):
+    """The structured forward (lib/controller_evaluation.py:863-886) with the bf16 path's roundings: inputs, weights
+    and hidden activations in bf16, sums and biases wider, head output unrounded."""
+    sc = (1.0 / xscale).astype(np.float32) if xscale is not None else np.ones(x.shape[1], np.float32)
+
+    def mlp(a, b):
+        z = [a.astype(np.float32) * sc] + ([b.astype(np.float32)] if b is not None else []) + [xs.astype(np.float32) * sc, us.astype(np.float32)]
+        h = _bf16(np.concatenate(z, axis=1)).astype(np.float64)
+        nl = (len(W) + 1) // 2
+        for l in range(nl - 1):
+            h = h @ _bf16(W[2 * l]).astype(np.float64) + W[2 * l + 1].astype(np.float32).astype(np.float64)
+            h = _bf16(np.maximum(h, 0.0)).astype(np.float64)
+        return (h @ _bf16(W[-1]).astype(np.float64)).astype(np.float32).astype(np.float64)
+    return us + (mlp(x, uprev) - mlp(xs, us if uprev is not None else None))
+
+
+@pytest.mark.parametrize("hid,withu,B,mb", [(832, False, 700, 512), (832, True, 40, 128), (960, False, 1300, 1024),
+                                            (448, True, 300, 256), (416, False, 257, 128), (1024, False, 520, 512)])
+def test_nn_bf16_wide_tile_kernel_shapes(hid, withu, B, mb):
+    """The 256 x 208-tile kernel of the hidden layers (widths >= 416): the reference's CDU widths 832...1024
+    (cdu_train.py:77-80) incl. a partial last column tile, one row panel only, several sub-batches, both layer
+    types -- against a numpy forward with the same bf16 roundings.  Tolerance 4e-3 of the output scale (f32
+    accumulation order can move a hidden activation by one bf16 ulp, 2^-8 relative)."""
+    from industrial_nnmpc_2021_amd.nn import StructuredNN
+    rng = np.random.default_rng(hid + B)
+    nx, nu = 252, 32
+    dims = [2 * nx + (2 if withu else 1) * nu, hid, hid, hid, nu]
+    W = []
+    for i in range(4):
+        W.append(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i]))
+        if i < 3:
+            W.append(0.05 * rng.standard_normal(dims[i + 1]))
+    x, xs = rng.standard_normal((B, nx)), 0.3 * rng.standard_normal((B, nx))
+    us, up = rng.uniform(-.5, .5, (B, nu)), rng.uniform(-1, 1, (B, nu))
+    xscale = rng.uniform(0.5, 2.0, nx)
+    net = StructuredNN(W, nx, nu, nnwithuprev=withu, xscale=xscale, max_batch=mb, use_bf16=True)
+    u = net.forward(x, up if withu else None, xs, us)
+    ref = _bf16_forward(W, x, up if withu else None, xs, us, xscale)
+    assert np.abs(u - ref).max() <= 4e-3 * max(1.0, np.abs(ref).max()), np.abs(u - ref).max()
+    net.close()
+
+
 def test_warm_started_chains_equal_cold_and_save_factorizations():
     """Chain driver with the shifted previous active set as warm start: same trajectories
     (every solve is KKT-certified), fewer Cholesky factorisations."""
