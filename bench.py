@@ -105,16 +105,33 @@ def bench_nn(args, torch, dev, rank, world, dist):
                          device_ms_per_step=dm / args.steps, gemm_ms_per_step=gm / args.steps)
         net.close()
     if rank == 0:
-        f = res["f32"]
+        f, h = res["f32"], res["bf16"]
+        # HBM bytes per launch of the hidden-layer GEMMs from the PMC passes of profiles/r01i_pmc_nn.json (same batch,
+        # 262144 states per launch); algorithmic bytes = rows x (K + N) x element size, averaged over the 3 layers
+        pmc = os.path.join(ROOT, "profiles", "r01i_pmc_nn.json")
+        tr = {}
+        if os.path.exists(pmc) and B >= 262144:
+            for k, v in json.load(open(pmc))["kernels"].items():
+                tr[k.split("::")[-1].split("<")[0]] = v["hbm_bytes_per_launch"]
+        rows = 2 * min(B, 262144)
+        kavg = (((dims[0] + 63) // 64) * 64 + 2 * hid) / 3.0
         out = {"metric": "structured-NN forward states/sec (CDU architecture)", "value": f["states_per_s"], "unit": "states/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": f["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"cdu_neural_network: RegulatorLayerWithoutUprev {dims}, {B} states per GPU per step",
                           "flops_per_state": flops_per_state},
-               "roofline": {"kernel": "gemm_nt_f32_k", "bound": "mfma", "achieved": f["gemm_TFLOPs"], "peak": FP32_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": f["gemm_TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": None},
+               "roofline": {"kernel": "gemm_nt_f32_k (128 x 128 tiles, v_mfma_f32_32x32x2_f32, bias + ReLU fused)", "bound": "mfma",
+                            "achieved": f["gemm_TFLOPs"], "peak": FP32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": f["gemm_TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": tr.get("gemm_nt_f32_k"),
+                            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_nn.json)",
+                            "algorithmic_bytes_per_launch": rows * (896 + 896) * 4,
+                            "algorithmic_flops": "2 passes x 2 x sum(d_in d_out) per state, unpadded (SURVEY 8d)"},
                "parity": {"max_rel_err_vs_fp64_oracle": f["max_rel_err_vs_fp64_oracle"]},
-               "bf16": dict(res["bf16"], peak_TFLOPs=2500.0, frac=res["bf16"]["gemm_TFLOPs"] / 2500.0)}
+               "bf16": dict(h, roofline={"kernel": "gemm_nt_bf16_wide_k (256 x 208 tiles, v_mfma_f32_16x16x32_bf16, persistent workgroups)",
+                                         "bound": "mfma", "achieved": h["gemm_TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
+                                         "frac": h["gemm_TFLOPs"] / 2500.0, "traffic": tr.get("gemm_nt_bf16_wide_k"),
+                                         "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_nn.json)",
+                                         "algorithmic_bytes_per_launch": rows * (kavg + hid) * 2})}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

@@ -65,6 +65,8 @@ struct AsmDev {
   const double* x0;                // [nseg][ka] padded initial states (for the certificate)
   int ka;
   const double* H;                 // [np][np] fp64 inverse Hessian
+  const float* H32;                // the same rounded to f32 (operand of the f32 GEMM; the f32 rounds gather S from it: same values as
+                                   // rounding the fp64 entries on the fly, half the bytes)
   const double* lb;                // [nseg][nu]
   const double* ub;
   const double* xunc;              // [nseg][np]
@@ -677,11 +679,12 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gj = 16 * J + N::kr(lq, r);
-        const double* Hr = d.H + (size_t)idx[min(gj, m - 1)] * d.np;
+        using HT = typename std::conditional<N::F32, float, double>::type;
+        const HT* Hr = (N::F32 ? reinterpret_cast<const HT*>(d.H32) : reinterpret_cast<const HT*>(d.H)) + (size_t)idx[min(gj, m - 1)] * d.np;
 #pragma unroll
         for (int I = J; I < MB; ++I) {                     // unconditional (clamped) loads, then select
           const int gi = 16 * I + li;
-          const double v = Hr[gcol[I]];
+          const HT v = Hr[gcol[I]];
           const T e = (gi < m && gj < m) ? (T)(-v) : (gi == gj ? T(-1) : T(0));
           if (J < NL && I > J) lt[slot(I, J) * 256 + r * 64] = e;
           else C[asm_tix(I, J)][r] = e;

@@ -882,7 +882,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
