@@ -77,19 +77,24 @@ def bench_nn(args, torch, dev, rank, world, dist):
     us = torch.rand((B, nu), dtype=torch.float64, device=dev, generator=g) - 0.5
     u = torch.empty((B, nu), dtype=torch.float64, device=dev)
     flops_per_state = 2 * 2 * sum(dims[i] * dims[i + 1] for i in range(4))   # both passes
+    hidden_flops_per_state = 2 * 2 * sum(dims[i] * dims[i + 1] for i in range(3))   # the three hidden-layer GEMMs
     res = {}
     for mode in ("f32", "bf16"):
         net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu),
                            max_batch=262144, use_bf16=(mode == "bf16"))
-        for _ in range(args.warmup):
+        # 6 extra untimed forwards before the W warmup steps: on every box tried, ONE forward of the first ~100 ms of
+        # sustained MFMA load starts ~40 ms late (device time of that call unchanged: the stream just starts later),
+        # then none for the rest of the run; with K of a few steps that one stall would be a third of the timed region
+        for _ in range(6 + args.warmup):
             net.forward_device(B, x, None, xs, us, u)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        t0 = time.perf_counter(); gm = 0.0; dm = 0.0
+        t0 = time.perf_counter(); gm = 0.0; dm = 0.0; hm = 0.0; hl = 0
         for _ in range(args.steps):
             net.forward_device(B, x, None, xs, us, u)
             gm += net.last_ms()[0]; dm += net.last_ms()[1]
+            hm += net.last_hidden_ms()[0]; hl += net.last_hidden_ms()[1]
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -102,7 +107,9 @@ def bench_nn(args, torch, dev, rank, world, dist):
         err = float(np.abs(u[:k].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()))
         res[mode] = dict(states_per_s=world * B * args.steps / dt, ms_per_step=1e3 * dt / args.steps,
                          gemm_TFLOPs=flops_per_state * B * args.steps / (gm * 1e-3) / 1e12, max_rel_err_vs_fp64_oracle=err,
-                         device_ms_per_step=dm / args.steps, gemm_ms_per_step=gm / args.steps)
+                         device_ms_per_step=dm / args.steps, gemm_ms_per_step=gm / args.steps,
+                         hidden_TFLOPs=hidden_flops_per_state * B * args.steps / (hm * 1e-3) / 1e12,
+                         hidden_launches=hl, hidden_avg_launch_ms=hm / max(1, hl))
         net.close()
     if rank == 0:
         f, h = res["f32"], res["bf16"]
@@ -121,15 +128,18 @@ def bench_nn(args, torch, dev, rank, world, dist):
                "config": {"workload": f"cdu_neural_network: RegulatorLayerWithoutUprev {dims}, {B} states per GPU per step",
                           "flops_per_state": flops_per_state},
                "roofline": {"kernel": "gemm_nt_f32_k (128 x 128 tiles, v_mfma_f32_32x32x2_f32, bias + ReLU fused)", "bound": "mfma",
-                            "achieved": f["gemm_TFLOPs"], "peak": FP32_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": f["gemm_TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": tr.get("gemm_nt_f32_k"),
+                            "achieved": f["hidden_TFLOPs"], "peak": FP32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": f["hidden_TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": tr.get("gemm_nt_f32_k"),
+                            "launches": f["hidden_launches"], "avg_launch_ms": f["hidden_avg_launch_ms"],
                             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_nn.json)",
                             "algorithmic_bytes_per_launch": rows * (896 + 896) * 4,
                             "algorithmic_flops": "2 passes x 2 x sum(d_in d_out) per state, unpadded (SURVEY 8d)"},
                "parity": {"max_rel_err_vs_fp64_oracle": f["max_rel_err_vs_fp64_oracle"]},
                "bf16": dict(h, roofline={"kernel": "gemm_nt_bf16_wide_k (256 x 208 tiles, v_mfma_f32_16x16x32_bf16, persistent workgroups)",
-                                         "bound": "mfma", "achieved": h["gemm_TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
-                                         "frac": h["gemm_TFLOPs"] / 2500.0, "traffic": tr.get("gemm_nt_bf16_wide_k"),
+                                         "bound": "mfma", "achieved": h["hidden_TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
+                                         "frac": h["hidden_TFLOPs"] / 2500.0, "traffic": tr.get("gemm_nt_bf16_wide_k"),
+                                         "launches": h["hidden_launches"], "avg_launch_ms": h["hidden_avg_launch_ms"],
+                                         "algorithmic_flops": "2 passes x 2 x (d_in h + 2 h^2) per state over the three hidden-layer launches (gemm_TFLOPs: all four GEMMs incl. the HBM-bound head)",
                                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_nn.json)",
                                          "algorithmic_bytes_per_launch": rows * (kavg + hid) * 2})}
         print(json.dumps(out))

@@ -165,6 +165,10 @@ int nnmpc_nn_destroy(nnmpc_nn* h);
 int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* uprev,
                      const double* xs, const double* us, double* u, int32_t ptr_kind);
 int nnmpc_nn_last_ms(nnmpc_nn* h, double* gemm_ms, double* total_ms);
+/* hipEvent time of the hidden-layer GEMM launches of the last forward and their number (bench.py: roofline of the
+ * dominant kernel from its own launches; the reference only has time.time() pairs around the whole call,
+ * lib/controller_evaluation.py:849-860) */
+int nnmpc_nn_last_hidden_ms(nnmpc_nn* h, double* hidden_ms, int32_t* launches);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ class QpStats(C.Structure):
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",
            "nnmpc_qp_solve_batch_warm", "nnmpc_qp_set_inverse",
            "nnmpc_qp_set_profiling", "nnmpc_qp_get_stats", "nnmpc_qp_debug_factor_solve",
-           "nnmpc_nn_create", "nnmpc_nn_destroy", "nnmpc_nn_forward", "nnmpc_nn_last_ms"]
+           "nnmpc_nn_create", "nnmpc_nn_destroy", "nnmpc_nn_forward", "nnmpc_nn_last_ms", "nnmpc_nn_last_hidden_ms"]
 
 _lib = None
 
@@ -79,6 +79,8 @@ def load():
     lib.nnmpc_nn_forward.argtypes = [vp, i32, dp, dp, dp, dp, dp, i32]
     lib.nnmpc_nn_last_ms.restype = i32
     lib.nnmpc_nn_last_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.nnmpc_nn_last_hidden_ms.restype = i32
+    lib.nnmpc_nn_last_hidden_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 

@@ -15,6 +15,8 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <stdlib.h>
 #include "../../include/nnmpc.h"
 #include "gemm_kernels.h"
 #include "tile_gemm_bf16.h"
@@ -89,7 +91,8 @@ struct nnmpc_nn {
   double *sx, *suprev, *sxs, *sus, *su;  // staging for host pointers
   hipStream_t stream;
   hipEvent_t e0, e1;
-  std::vector<hipEvent_t> eg;   // (start, end) of the GEMMs of every sub-batch of a call
+  std::vector<hipEvent_t> eg;   // (start, end of the hidden layers, end) of the GEMMs of every sub-batch of a call
+  double hidden_ms; int hidden_launches;
   double gemm_ms, total_ms;
   std::vector<void*> allocs;
 };
@@ -153,7 +156,7 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   h->use_bf16 = use_bf16 != 0;
   h->nlayers = nlayers; h->nx = nx; h->nu = nu; h->with_uprev = with_uprev; h->clip = ulb != nullptr;
   h->max_batch = ((std::max(max_batch, 1) + 127) / 128) * 128;
-  h->gemm_ms = h->total_ms = 0;
+  h->gemm_ms = h->total_ms = h->hidden_ms = 0; h->hidden_launches = 0;
   h->dims.assign(dims, dims + nlayers + 1);
   hipStreamCreate(&h->stream);
   hipEventCreate(&h->e0); hipEventCreate(&h->e1);
@@ -241,11 +244,13 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
   HIPCHK(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   const int nx = h->nx, nu = h->nu, MB = h->max_batch;
+  static const bool dbg = getenv("NNMPC_DEBUG_TIMING") != nullptr;
+  const auto T0 = std::chrono::steady_clock::now();
   double gemm_ms = 0.0;
   hipEventRecord(h->e0, s);
   size_t nsub = 0;
   for (int b0 = 0; b0 < B; b0 += MB, ++nsub) {
-    while (h->eg.size() < 2 * (nsub + 1)) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->eg.push_back(e); }
+    while (h->eg.size() < 3 * (nsub + 1)) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); h->eg.push_back(e); }
     const int nb = std::min(MB, B - b0);
     const int Bp = ((nb + 127) / 128) * 128;
     const double *dx, *dup, *dxs, *dus; double* du;
@@ -265,7 +270,7 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
     else
       hipLaunchKernelGGL(nn_assemble_k<float>, dim3(8192), dim3(h->kpad[0] % 192 == 0 ? 192 : 256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
                          h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
-    hipEventRecord(h->eg[2 * nsub], s);
+    hipEventRecord(h->eg[3 * nsub], s);
     int cur = 0;
     const int M = 2 * Bp;
     for (int l = 0; l < h->nlayers; ++l) {
@@ -273,6 +278,7 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       float* C = h->act[cur ^ 1];
       const float* A = h->act[cur];
       const bool last = l == h->nlayers - 1;
+      if (last) hipEventRecord(h->eg[3 * nsub + 1], s);    // end of the hidden layers
       if (h->use_bf16) {
         const bf16raw* A16 = reinterpret_cast<const bf16raw*>(A);
         const int K16 = h->k16[l], ldc = h->ldc16[l];
@@ -294,21 +300,41 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       }
       cur ^= 1;
     }
-    hipEventRecord(h->eg[2 * nsub + 1], s);
+    hipEventRecord(h->eg[3 * nsub + 2], s);
     hipLaunchKernelGGL(nn_combine_k, dim3(1024), dim3(256), 0, s, du, h->act[cur], h->npad[h->nlayers - 1], Bp,
                        nb, nu, dus, h->ulb, h->uub, h->clip);
     if (ptr_kind == NNMPC_HOST) {                           // the staging buffers are reused by the next sub-batch
       HIPCHK(hipMemcpyAsync(u + (size_t)b0 * nu, h->su, (size_t)nb * nu * 8, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(stream_sync(s));
     }
   }
   hipEventRecord(h->e1, s);
-  HIPCHK(hipStreamSynchronize(s));
+  const auto T1 = std::chrono::steady_clock::now();
+  HIPCHK(stream_sync(s));
+  const auto T2 = std::chrono::steady_clock::now();
   HIPCHK(hipGetLastError());
   float tot = 0.f;
   hipEventElapsedTime(&tot, h->e0, h->e1);
-  for (size_t i = 0; i < nsub; ++i) { float ms = 0.f; hipEventElapsedTime(&ms, h->eg[2 * i], h->eg[2 * i + 1]); gemm_ms += ms; }
+  double hid = 0.0;
+  for (size_t i = 0; i < nsub; ++i) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, h->eg[3 * i], h->eg[3 * i + 2]); gemm_ms += ms;
+    hipEventElapsedTime(&ms, h->eg[3 * i], h->eg[3 * i + 1]); hid += ms;
+  }
+  h->hidden_ms = hid; h->hidden_launches = (int)nsub * (h->nlayers - 1);
   h->gemm_ms = gemm_ms; h->total_ms = tot;
+  if (dbg) {
+    const auto T3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "nnmpc_nn_forward: enqueue %.3f ms, wait %.3f ms, post %.3f ms, device %.3f ms\n", ms(T0, T1), ms(T1, T2), ms(T2, T3), (double)tot);
+  }
+  return NNMPC_OK;
+}
+
+int nnmpc_nn_last_hidden_ms(nnmpc_nn* h, double* hidden_ms, int32_t* launches) {
+  if (!h) return NNMPC_EINVAL;
+  if (hidden_ms) *hidden_ms = h->hidden_ms;
+  if (launches) *launches = h->hidden_launches;
   return NNMPC_OK;
 }
 

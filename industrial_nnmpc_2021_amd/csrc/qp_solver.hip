@@ -834,7 +834,7 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
     hipLaunchKernelGGL(stage_pre_k, dim3(rows), dim3(256), 0, s, d);
     HIPCHK(hipMemcpyAsync(cnt, d.counters, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&issued, d.next_prob, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_sync(s));
     if (cnt[CNT_ACTIVE] == 0 && issued >= nprob) break;
     any_ipm = cnt[CNT_IPM] > 0;
     any_polish = cnt[CNT_POLISH] > 0;
@@ -856,7 +856,7 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
       }
     }
   }
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_sync(s));
   HIPCHK(hipGetLastError());
   h->stats.problems += nprob;
   return 0;
@@ -921,7 +921,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       hipLaunchKernelGGL(asm_bins_b_k, dim3((nprob + 1023) / 1024), dim3(1024), 0, s, a);
     }
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_sync(s));
     const int n64 = cnt[2], n32 = cnt[ASM_CNT_ROWS32], nrun = n64 + n32;   // solved in fp64 / f32 this round
     if (h->profiling)                                   // flops of the full-width pass that opened this round
     {
@@ -940,7 +940,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS) * 8 + ((h->n + 15) / 16) * 16;
       hipLaunchKernelGGL(asm_tail_k, dim3(nrun), dim3(256), lds_tail, s, a, a.max_rounds);
       HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(stream_sync(s));
       h->stats.asm_rounds += 1;
       rounds = 0;                                         // (regular exit: the counters just read are final)
       break;
@@ -997,7 +997,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   // certification with P itself (rows the inverse-error bound could not certify): q = tq x0 and px = x P
   if (rounds >= 2 * a.max_rounds + 2) {                  // left by the round cap: the last counters are not final
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_sync(s));
   }
   h->stats.asm_full_checks += cnt[ASM_CNT_DONE];
   if (cnt[ASM_CNT_DONE] > 0) {
@@ -1007,7 +1007,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   hipLaunchKernelGGL(asm_certify_k, dim3(nprob), dim3(256), 0, s, a, h->pscale);
   std::vector<int> st(nprob);
   HIPCHK(hipMemcpyAsync(st.data(), h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(stream_sync(s));
   HIPCHK(hipGetLastError());
   std::vector<int> fb;
   for (int p = 0; p < nprob; ++p) if (st[p] != 0) fb.push_back(p);
@@ -1048,7 +1048,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   if (!rc) {
     hipLaunchKernelGGL(asm_scatter_k, dim3(cntf), dim3(128), 0, s, u_dev, act_dev, st_dev, it_dev, uc, actc, stc, itc,
                        list, cntf, h->n, h->words);
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(stream_sync(s));
   }
   hipFree(guessc); hipFree(list); hipFree(x0c); hipFree(lbc); hipFree(ubc); hipFree(uc); hipFree(actc); hipFree(stc); hipFree(itc);
   h->stats.problems += nprob - cntf;   // solve_segment counted the fallback ones
@@ -1270,14 +1270,14 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
       for (int k = 0; k < n_aug; ++k) ktr[(size_t)k * np + r] = Kunc[(size_t)r * n_aug + k];
     HIPCHK(hipMemcpy(kt, ktr.data(), ktr.size() * 8, hipMemcpyHostToDevice));
     gemm64(h, tmp, np, h->P64, np, h->H64, np, np, np, np);                 // P Pinv (Pinv symmetric)
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h->stream));
     std::vector<double> c((size_t)np * np);
     HIPCHK(hipMemcpy(c.data(), tmp, c.size() * 8, hipMemcpyDeviceToHost));
     double e2 = 0.0;
     for (int r = 0; r < n; ++r)
       for (int cc = 0; cc < n; ++cc) e2 = std::max(e2, std::fabs(c[(size_t)r * np + cc] - (r == cc ? 1.0 : 0.0)));
     gemm64(h, tmp, kap, h->P64, np, kt, np, np, kap, np);                   // P Kunc  -> [np][kap]
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h->stream));
     HIPCHK(hipMemcpy(c.data(), tmp, (size_t)np * kap * 8, hipMemcpyDeviceToHost));
     std::vector<double> tqh((size_t)np * ka);
     HIPCHK(hipMemcpy(tqh.data(), h->tq64, tqh.size() * 8, hipMemcpyDeviceToHost));
@@ -1386,7 +1386,7 @@ int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const do
   if (h->profiling) {
     size_t e1 = ev_get(h);
     hipEventRecord(h->ev_pool[e1], h->stream);
-    hipStreamSynchronize(h->stream);
+    stream_sync(h->stream);
     h->ev_recs.push_back({3, e_tot0, e1, 0.0});
     ev_collect(h);
   }
@@ -1416,13 +1416,13 @@ int nnmpc_qp_debug_factor_solve(nnmpc_qp* h, int32_t B, const float* dvec, const
   HIPCHK(hipMemset(d.fail, 0, rows * 4));
   factor_dispatch(h, rows, B);
   solve_dispatch(h, rows, d.f_factor);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(stream_sync(h->stream));
   HIPCHK(hipGetLastError());
   std::vector<float> so((size_t)rows * h->np);
   HIPCHK(hipMemcpy(so.data(), d.sol, so.size() * 4, hipMemcpyDeviceToHost));
   for (int p = 0; p < B; ++p)
     for (int r = 0; r < h->n; ++r) sol[(size_t)p * h->n + r] = so[(size_t)p * h->np + r];
-  if (h->profiling) { hipStreamSynchronize(h->stream); ev_collect(h); }
+  if (h->profiling) { stream_sync(h->stream); ev_collect(h); }
   return NNMPC_OK;
 }
 

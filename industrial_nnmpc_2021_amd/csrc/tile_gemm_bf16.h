@@ -324,13 +324,18 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
         }
       }
       int row = lane / npc, c = lane - row * npc;            // piece q = lane + 64 i -> (row, c) = (q / npc, q % npc)
+      const int dr = 64 / npc, dc = 64 % npc;
 #pragma unroll 1
-      for (int i = 0; i < WNT; ++i) {                        // rolled: the registers belong to the loads in flight
-        if (row < 32) {
-          const u32x4 v = *reinterpret_cast<const u32x4*>(er + row * ESTRIDE + 16 * c);
-          if (n0 + 16 * WNT * wn + 8 * c < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)(32 * h + row) * ldc + 8 * c) = v;
-        }
-        c += 64 % npc; row += 64 / npc;
+      for (int i = 0; i < WNT; i += 2) {                     // two pieces per trip (their LDS reads overlap); not unrolled
+        int row1 = row + dr, c1 = c + dc;                    // further: the registers belong to the loads in flight
+        if (c1 >= npc) { c1 -= npc; ++row1; }
+        const bool ok0 = row < 32, ok1 = i + 1 < WNT && row1 < 32;
+        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+        if (ok0) v0 = *reinterpret_cast<const u32x4*>(er + row * ESTRIDE + 16 * c);
+        if (ok1) v1 = *reinterpret_cast<const u32x4*>(er + row1 * ESTRIDE + 16 * c1);
+        if (ok0 && n0 + 16 * WNT * wn + 8 * c < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)(32 * h + row) * ldc + 8 * c) = v0;
+        if (ok1 && n0 + 16 * WNT * wn + 8 * c1 < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)(32 * h + row1) * ldc + 8 * c1) = v1;
+        row = row1 + dr; c = c1 + dc;
         if (c >= npc) { c -= npc; ++row; }
       }
     }

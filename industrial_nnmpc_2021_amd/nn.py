@@ -67,3 +67,9 @@ class StructuredNN:
         g, t = C.c_double(), C.c_double()
         self._lib.nnmpc_nn_last_ms(self._h, C.byref(g), C.byref(t))
         return g.value, t.value
+
+    def last_hidden_ms(self):
+        """(hipEvent ms of the hidden-layer GEMMs of the last forward, number of those launches)."""
+        g, k = C.c_double(), C.c_int32()
+        self._lib.nnmpc_nn_last_hidden_ms(self._h, C.byref(g), C.byref(k))
+        return g.value, k.value
