@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--method", default="auto", choices=["auto", "pdip", "asm"],
                     help="auto: shared-inverse active-set pass + PDIP for what it leaves; pdip: PDIP path only")
     ap.add_argument("--no-pdip", action="store_true", help="skip the extra PDIP-path measurement")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (host buffers either side)")
     ap.add_argument("--pdip-batch", type=int, default=0)
     args = ap.parse_args()
 
@@ -354,6 +355,35 @@ def main():
                                 "active_sets_equal": bool(torch.equal(act2, act[:Bp])),
                                 "roofline": panel_roofline(s2)}
             qp2.close()
+        # ---- the same batch with host buffers either side (never `value`): pinned host tensors -> HBM over PCIe, the
+        # solve, first moves (what simulate_offline keeps, lib/linearMPC.py:856) or full sequences back to the host
+        if world == 1 and not args.no_host_io:
+            qp.set_profiling(False)
+            xh, lbh, ubh = (t.cpu().pin_memory() for t in (x0, lb, ub))
+            fh = torch.empty((B, nu), dtype=torch.float64).pin_memory()
+            uh = torch.empty((B, n), dtype=torch.float64).pin_memory()
+            hio = {}
+            for name, full in (("first_move", False), ("full_sequence", True)):
+                best = None
+                for _ in range(2):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    x0.copy_(xh, non_blocking=True); lb.copy_(lbh, non_blocking=True); ub.copy_(ubh, non_blocking=True)
+                    torch.cuda.synchronize()
+                    qp.solve_batch_device(B, x0, lb, ub, u, act, status, iters)
+                    if full:
+                        uh.copy_(u, non_blocking=True)
+                    else:
+                        fh.copy_(u[:, :nu] + us, non_blocking=True)
+                    torch.cuda.synchronize(); d = time.perf_counter() - t1
+                    best = d if best is None else min(best, d)
+                hio[name + "_solves_per_s"] = B / best
+                hio[name + "_ms"] = 1e3 * best
+            hio["bytes_in"] = int(xh.numel() + lbh.numel() + ubh.numel()) * 8
+            hio["bytes_out_first_move"] = B * nu * 8
+            hio["bytes_out_full_sequence"] = B * n * 8
+            hio["note"] = "PCIe-inclusive: pinned host buffers -> HBM, solve, results -> pinned host buffers; best of 2"
+            out["host_io"] = hio
+            del uh, fh
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, x0_h, lb_h, ub_h,
                                                budget_s=20.0 if args.workload == "cdu" else 10.0, workload=args.workload)

@@ -130,7 +130,11 @@ void launch_layer16_wide(hipStream_t s, __bf16* C, int ldc, const bf16raw* A, si
   const int ntn = (ldc + WBN - 1) / WBN;
   const int npg = std::max(1, 32 / ntn);                    // panel groups per XCD: 8 * npg * ntn workgroups <= 256 CUs
   // the kernel addresses A with 32-bit byte offsets: slices of less than 2^31 bytes
-  const int max_rows = (int)(((size_t)1 << 31) / (lda * 2) / WBM) * WBM - WBM;
+  int max_rows = (int)(((size_t)1 << 31) / (lda * 2) / WBM) * WBM - WBM;
+  if (const char* e = getenv("NNMPC_WIDE_MAX_ROWS")) {      // tests: force several slices on a small batch
+    const int v = atoi(e) / WBM * WBM;
+    if (v >= WBM) max_rows = std::min(max_rows, v);
+  }
   for (int m = 0; m < M; m += max_rows) {
     const int rows = std::min(max_rows, M - m), ntm = rows / WBM;
     hipLaunchKernelGGL((gemm_nt_bf16_wide_k<RELU, BIAS>), dim3(8 * npg * ntn), dim3(512), W_LDS_BYTES, s,

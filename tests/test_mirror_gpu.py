@@ -194,6 +194,28 @@ def test_nn_bf16_wide_tile_kernel_shapes(hid, withu, B, mb):
     net.close()
 
 
+def test_nn_bf16_wide_tile_kernel_row_slices(monkeypatch):
+    """The wide-tile kernel addresses its input with 32-bit byte offsets; the launcher cuts inputs of 2^31 bytes and
+    more into row slices.  NNMPC_WIDE_MAX_ROWS forces that path on a small batch: same result as one slice."""
+    from industrial_nnmpc_2021_amd.nn import StructuredNN
+    rng = np.random.default_rng(11)
+    nx, nu, hid, B = 252, 32, 832, 900
+    dims = [2 * nx + nu, hid, hid, hid, nu]
+    W = []
+    for i in range(4):
+        W.append(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i]))
+        if i < 3:
+            W.append(0.05 * rng.standard_normal(dims[i + 1]))
+    x, xs = rng.standard_normal((B, nx)), 0.3 * rng.standard_normal((B, nx))
+    us = rng.uniform(-.5, .5, (B, nu))
+    net = StructuredNN(W, nx, nu, nnwithuprev=False, max_batch=1024, use_bf16=True)
+    one = net.forward(x, None, xs, us)
+    monkeypatch.setenv("NNMPC_WIDE_MAX_ROWS", "512")          # 2 * 1024 rows -> 4 slices
+    cut = net.forward(x, None, xs, us)
+    net.close()
+    assert np.array_equal(one, cut)
+
+
 def test_warm_started_chains_equal_cold_and_save_factorizations():
     """Chain driver with the shifted previous active set as warm start: same trajectories
     (every solve is KKT-certified), fewer Cholesky factorisations."""
