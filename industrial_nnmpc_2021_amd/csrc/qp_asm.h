@@ -1110,10 +1110,19 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       unsigned char dc = 255;
       double x;
       if (sr == 0) {
-        const double* Hr = d.H + (size_t)r * d.np;
-        double acc = 0.0;
-        for (int i = 0; i < m; ++i) acc += Hr[idx[i]] * rA[i];
-        x = d.xunc[o + r] - acc;
+        // (lam H)[r] = sum_i lam_i H[idx_i][r], the GEMM's indexing: consecutive threads read consecutive columns of
+        // row idx_i (H[r][idx_i] -- the same number, H is symmetric -- would touch one cache line per thread)
+        const double* Hc = d.H + r;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int i = 0;
+        for (; i + 4 <= m; i += 4) {
+          a0 += Hc[(size_t)idx[i] * d.np] * rA[i];
+          a1 += Hc[(size_t)idx[i + 1] * d.np] * rA[i + 1];
+          a2 += Hc[(size_t)idx[i + 2] * d.np] * rA[i + 2];
+          a3 += Hc[(size_t)idx[i + 3] * d.np] * rA[i + 3];
+        }
+        for (; i < m; ++i) a0 += Hc[(size_t)idx[i] * d.np] * rA[i];
+        x = d.xunc[o + r] - ((a0 + a1) + (a2 + a3));
         if (x > ub + d.bound_tol) dc = 1; else if (x < lb - d.bound_tol) dc = 2;
       } else x = sr == 1 ? ub : lb;
       d.u_out[(size_t)p * d.n + r] = x;                      // final once nothing changes
