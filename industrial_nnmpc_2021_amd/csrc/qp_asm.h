@@ -896,14 +896,16 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   const int* idx = d.idxg + (size_t)p * d.max_active;
   // Exchange rule (block principal pivoting with Murty's fallback: Judice & Pires 1994, Kim & Park 2011): all
   // infeasible indices change sides as long as their number keeps falling -- with ASM_GRACE rounds of grace --,
-  // otherwise only the infeasible variable with the largest index does.  The plain all-at-once rule cycles on
+  // otherwise only the infeasible variable with the SMALLEST index does (Murty's least-index rule: the earliest MPC
+  // stage first -- taking the largest index instead needed several times as many exchanges on the stragglers of the
+  // cond-4e7 plant).  The plain all-at-once rule cycles on
   // ill-conditioned Hessians (6 of 131 072 samples of the cond-4e7 CSTRs-size plant); the fallback is finite.
   __shared__ unsigned short ch_r[4][8][64];                  // this lane's first changes: index, new state
   __shared__ unsigned char ch_s[4][8][64];
   const int wv = threadIdx.x >> 6;
-  int chg = 0, rmax = -1;
+  int chg = 0, rmax = 0x7fffffff;                            // the index a single exchange takes: the smallest infeasible one
   double l1 = 0.0, lmin = 1e300;
-  auto scan = [&](int mode) {                                // 0: count and record, 1: apply all, 2: apply only index rmax
+  auto scan = [&](int mode) {                                // 0: count and record, 1: apply all, 2: apply only index rmax (the smallest infeasible one)
     for (int r = lane; r < W; r += 64) {                     // free variables of the window: feasibility
       if (st[r]) continue;
       const int k = r % d.nu;
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
       const double x = d.xunc[o + r] - (f32_phase ? (double)d.xh32[orow + r] : d.xh[orow + r]);
       const int ns = x > ub + d.bound_tol ? 1 : (x < lb - d.bound_tol ? 2 : 0);
       if (!ns) continue;
-      if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)r; ch_s[wv][chg][lane] = (unsigned char)ns; } ++chg; rmax = max(rmax, r); }
+      if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)r; ch_s[wv][chg][lane] = (unsigned char)ns; } ++chg; rmax = min(rmax, r); }
       else if (mode == 1 || r == rmax) st[r] = (unsigned char)ns;
     }
     for (int i = lane; i < m; i += 64) {                     // active bounds: multiplier signs (keep iff multiplier > 0)
@@ -919,14 +921,14 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
       const double l = f32_phase ? (double)d.lam32[orow + a] : d.lam[orow + a];
       if (mode == 0) { l1 += fabs(l); lmin = fmin(lmin, fabs(l)); }
       if (!((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0))) continue;
-      if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)a; ch_s[wv][chg][lane] = 0; } ++chg; rmax = max(rmax, a); }
+      if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)a; ch_s[wv][chg][lane] = 0; } ++chg; rmax = min(rmax, a); }
       else if (mode == 1 || a == rmax) st[a] = 0;
     }
   };
   scan(0);
   const int mych = chg;
   const bool overflow = __any(mych > 8) || d.n > 65535;
-  for (int off = 32; off > 0; off >>= 1) { chg += __shfl_xor(chg, off); rmax = max(rmax, __shfl_xor(rmax, off)); }
+  for (int off = 32; off > 0; off >>= 1) { chg += __shfl_xor(chg, off); rmax = min(rmax, __shfl_xor(rmax, off)); }
   const int tot = chg;
   if (tot > 0) {
     int single = 0;
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
     if (m > d.max_active) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
     if (asm_tile_solve(d, p, m, idx, rA, Yt, m <= 16 * ASM_TAIL_MB ? Tl : Tg, &s_bad)) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
     // x and the tests, decisions recorded (255: stays)
-    int ninf = 0, rmax = -1;
+    int ninf = 0, rmax = 0x7fffffff;                         // rmax: the infeasible index the single exchange takes (the smallest)
     double l1 = 0.0, lmin = 1e300;
     for (int r = tid; r < d.n; r += 256) {
       const int sr = st[r];
@@ -1127,24 +1129,24 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       } else x = sr == 1 ? ub : lb;
       d.u_out[(size_t)p * d.n + r] = x;                      // final once nothing changes
       dec[r] = dc;
-      if (dc != 255) { ++ninf; rmax = max(rmax, r); }
+      if (dc != 255) { ++ninf; rmax = min(rmax, r); }
     }
     __syncthreads();                                         // dec of the free variables complete
     for (int i = tid; i < m; i += 256) {
       const int a = idx[i], sa = st[a];
       const double l = rA[i];
       l1 += fabs(l); lmin = fmin(lmin, fabs(l));
-      if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { dec[a] = 0; ++ninf; rmax = max(rmax, a); }
+      if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { dec[a] = 0; ++ninf; rmax = min(rmax, a); }
     }
     for (int off = 32; off > 0; off >>= 1) {
-      ninf += __shfl_xor(ninf, off); rmax = max(rmax, __shfl_xor(rmax, off));
+      ninf += __shfl_xor(ninf, off); rmax = min(rmax, __shfl_xor(rmax, off));
       l1 += __shfl_xor(l1, off); lmin = fmin(lmin, __shfl_xor(lmin, off));
     }
     __syncthreads();
     if (lane == 0) { wsum[wave] = ninf; s_i[wave] = rmax; s_d[wave] = l1; s_d[4 + wave] = lmin; }
     __syncthreads();
     ninf = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    rmax = max(max(s_i[0], s_i[1]), max(s_i[2], s_i[3]));
+    rmax = min(min(s_i[0], s_i[1]), min(s_i[2], s_i[3]));
     ++rounds;
     if (ninf == 0) {                                         // settled: certificate as in asm_update_k
       double x1 = 0.0;

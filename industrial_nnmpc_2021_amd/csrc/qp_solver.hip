@@ -323,7 +323,8 @@ __device__ int kkt_check(const QpDev& d, int p, int* shi, double* shd) {
   }
   // Exchange rule (block principal pivoting with single-exchange fallback, as in asm_update_k): every infeasible
   // index changes sides while their number keeps reaching new minima (POLISH_GRACE rounds of grace), after that only
-  // the one with the largest index -- the all-at-once rule can cycle for ever on ill-conditioned Hessians.
+  // the one with the SMALLEST index (Murty's least-index rule; earliest MPC stage first) -- the all-at-once rule can
+  // cycle for ever on ill-conditioned Hessians.
   int single = 0, rsel = -1;
   {
     const int best = d.pninf[p], grace = d.pgrace[p];
@@ -333,16 +334,17 @@ __device__ int kkt_check(const QpDev& d, int p, int* shi, double* shd) {
     else single = 1;
   }
   if (single) {
-    double rm = -1.0;
+    double rm = -1e300;                                      // minus the smallest infeasible index
     for (int r = tid; r < n; r += 256) {
       const int c = r % d.nu;
       const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
       const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
       const int s = d.st[o + r];
       const bool inf = s == 0 ? ((x > ub + d.bound_tol) || (x < lb - d.bound_tol)) : (s == 1 ? g >= 0.0 : g <= 0.0);
-      if (inf) rm = (double)r;
+      if (inf && -(double)r > rm) rm = -(double)r;
     }
-    rsel = (int)block_maxd(rm, shd);
+    rm = block_maxd(rm, shd);
+    rsel = rm > -1e299 ? (int)(-rm) : -1;
   }
   for (int r = tid; r < n; r += 256) {
     const int c = r % d.nu;
