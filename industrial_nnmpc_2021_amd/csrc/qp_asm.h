@@ -1078,13 +1078,53 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
 // latency.  asm_tail_k finishes them on the device: one workgroup per problem loops count -> fp64 solve (tiles in its
 // L2 slab) -> x over ALL columns (n |A| MACs straight from Pinv) -> exchange rule, until the set settles or the budget
 // is spent.  Same arithmetic and the same certificate as the round kernels; u goes to the caller's buffer.
+// ---- dense factor of the tail's single-exchange phase (see asm_tail_k): L (lower, fp64) of S = H_AA for up to
+// ASM_FM - 1 bounds in LDS, packed by rows: row i holds its columns 0..i + 1 (one spare slot: the entry a dropped
+// row leaves above the diagonal until the Givens rotations have removed it) at offset i (i + 3) / 2.  The routines
+// below run in ONE wave (DS operations of a wave complete in order; ASM_FENCE where a later read depends on an
+// earlier write of another lane).
+constexpr int ASM_FM = 160;
+constexpr int ASM_TAIL_GRACE = 2;
+constexpr int ASM_TAIL_AREA = ASM_FM * (ASM_FM + 3) / 2 > ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS
+                                  ? ASM_FM * (ASM_FM + 3) / 2 : ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS;   // doubles: tiles or factor
+constexpr int ASM_TAIL_EXTRA = ASM_FM * (4 + 8 + 8);      // al, rhs, work vector
+__device__ __forceinline__ int asm_frow(int i) { return i * (i + 3) / 2; }
+
+// v <- L^-1 v  (v[0..m) in LDS)
+__device__ __forceinline__ void asm_fwd(const double* Ld, double* v, int m, int lane) {
+  for (int k = 0; k < m; ++k) {
+    const double yk = v[k] / Ld[asm_frow(k) + k];
+    ASM_FENCE();
+    if (lane == 0) v[k] = yk;
+    for (int i = k + 1 + lane; i < m; i += 64) v[i] -= Ld[asm_frow(i) + k] * yk;
+    ASM_FENCE();
+  }
+}
+// v <- L^-T v
+__device__ __forceinline__ void asm_bwd(const double* Ld, double* v, int m, int lane) {
+  for (int k = m - 1; k >= 0; --k) {
+    const double* row = Ld + asm_frow(k);
+    const double lk = v[k] / row[k];
+    ASM_FENCE();
+    if (lane == 0) v[k] = lk;
+    for (int i = lane; i < k; i += 64) v[i] -= row[i] * lk;
+    ASM_FENCE();
+  }
+}
+
 __global__ __launch_bounds__(256) void asm_taillist_k(AsmDev d) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p < d.nseg && d.state[p] == ASM_RUN) d.biglist[atomicAdd(&d.counters[ASM_CNT_TAIL], 1)] = p;   // a few hundred at most
 }
+// Iterations of the block-exchange phase refactor the set from scratch (asm_tile_solve, as in the round kernels).  Once a
+// problem is down to SINGLE exchanges -- where the stragglers of an ill-conditioned plant spend hundreds of iterations --
+// the set changes by one index per iteration: the kernel then keeps a dense Cholesky factor in LDS and appends a row
+// (one forward substitution) or drops one (Givens rotations over the trailing columns) instead of gathering and
+// factoring |A|^2 entries again; multipliers by two substitutions.  Every accepted result still passes the fp64
+// certificate, so a factor that lost accuracy can only cost time (the problem then falls back to the PDIP path).
 __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_bad, wsum[4], s_i[4];
+  __shared__ int s_bad, wsum[4], s_i[4], s_m, s_fast;
   __shared__ double s_d[12];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= d.counters[ASM_CNT_TAIL]) return;
@@ -1092,23 +1132,77 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   double* rA = sm;                                           // [max_active] rhs -> lam
   double* Yt = rA + d.max_active;
   double* Tl = Yt + ASM_TS;                                  // tiles of sets of up to 16 ASM_TAIL_MB bounds (else: L2 slab)
-  unsigned char* dec = reinterpret_cast<unsigned char*>(Tl + ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS);   // [n] decisions
+  double* Ld = Tl;                                           // ... or the dense factor of the single-exchange phase
+  unsigned char* dec = reinterpret_cast<unsigned char*>(Tl + ASM_TAIL_AREA);   // [n] decisions
+  double* rhs = reinterpret_cast<double*>(dec + ((d.n + 15) / 16) * 16);   // [ASM_FM] x_unc,A - b_A in factor order
+  double* vv = rhs + ASM_FM;                                 // [ASM_FM] work vector
+  int* al = reinterpret_cast<int*>(vv + ASM_FM);             // [ASM_FM] active indices in factor order
   double* Tg = d.scratch + (size_t)blockIdx.x * ((size_t)(d.max_active / 16) * (d.max_active / 16 + 1) / 2 * ASM_TS);
   const size_t o = (size_t)p * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
   const int* idx = d.idxg + (size_t)p * d.max_active;
+  const double* lbp = d.lb + (size_t)p * d.nu;
+  const double* ubp = d.ub + (size_t)p * d.nu;
   int best = d.ninf_best[p], grace = d.alpha[p], hi = d.hi[p], rounds = d.rounds[p];
+  int single = 0;                                            // the previous iteration ended with a single exchange
+  int fast = 0, m = 0;                                       // dense factor valid for the current set (of size m)
   for (int it = 0; it < budget; ++it) {
-    const int m = asm_count_one(d, p, hi, wsum);
-    if (m > d.max_active) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
-    if (asm_tile_solve(d, p, m, idx, rA, Yt, m <= 16 * ASM_TAIL_MB ? Tl : Tg, &s_bad)) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
+    if (!fast) {
+      m = asm_count_one(d, p, hi, wsum);
+      if (m > d.max_active) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
+      if (single && m > 0 && m < ASM_FM) {
+        // ---- build the dense factor: gather the lower triangle, right-looking Cholesky (three barriers per column)
+        __syncthreads();                                       // idx (asm_count_one) complete
+        for (int i = tid; i < m; i += 256) {
+          const int a = idx[i];
+          al[i] = a;
+          rhs[i] = d.xunc[o + a] - (st[a] == 1 ? ubp[a % d.nu] : lbp[a % d.nu]);
+        }
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        for (int i = tid >> 4; i < m; i += 16) {
+          const double* Hr = d.H + (size_t)al[i] * d.np;
+          for (int j = tid & 15; j <= i; j += 16) Ld[asm_frow(i) + j] = Hr[al[j]];
+        }
+        for (int k = 0; k < m; ++k) {
+          __syncthreads();
+          const double piv = Ld[asm_frow(k) + k];
+          if (!(piv > 0.0)) { if (tid == 0) s_bad = 1; break; }        // uniform: every thread reads the same value
+          const double rs = 1.0 / sqrt(piv);
+          __syncthreads();
+          if (tid == 0) Ld[asm_frow(k) + k] = piv * rs;
+          for (int i = k + 1 + tid; i < m; i += 256) Ld[asm_frow(i) + k] *= rs;
+          __syncthreads();
+          for (int i = k + 1 + (tid >> 4); i < m; i += 16) {
+            const double lik = Ld[asm_frow(i) + k];
+            for (int j = k + 1 + (tid & 15); j <= i; j += 16) Ld[asm_frow(i) + j] -= lik * Ld[asm_frow(j) + k];
+          }
+        }
+        __syncthreads();
+        if (s_bad) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
+        fast = 1;
+      } else {
+        if (asm_tile_solve(d, p, m, idx, rA, Yt, m <= 16 * ASM_TAIL_MB ? Tl : Tg, &s_bad)) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
+      }
+    }
+    if (fast) {                                              // lam = L^-T L^-1 rhs  (wave 0)
+      if (wave == 0) {
+        for (int i = lane; i < m; i += 64) vv[i] = rhs[i];
+        ASM_FENCE();
+        asm_fwd(Ld, vv, m, lane);
+        asm_bwd(Ld, vv, m, lane);
+        for (int i = lane; i < m; i += 64) rA[i] = vv[i];
+      }
+      __syncthreads();
+    }
+    const int* lst = fast ? al : idx;                        // the set the multipliers rA[0..m) belong to
     // x and the tests, decisions recorded (255: stays)
-    int ninf = 0, rmax = 0x7fffffff;                         // rmax: the infeasible index the single exchange takes (the smallest)
+    int ninf = 0, rmin = 0x7fffffff;                         // rmin: the infeasible index a single exchange takes (the smallest)
     double l1 = 0.0, lmin = 1e300;
     for (int r = tid; r < d.n; r += 256) {
       const int sr = st[r];
       const int k = r % d.nu;
-      const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
+      const double lb = lbp[k], ub = ubp[k];
       unsigned char dc = 255;
       double x;
       if (sr == 0) {
@@ -1118,36 +1212,41 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int i = 0;
         for (; i + 4 <= m; i += 4) {
-          a0 += Hc[(size_t)idx[i] * d.np] * rA[i];
-          a1 += Hc[(size_t)idx[i + 1] * d.np] * rA[i + 1];
-          a2 += Hc[(size_t)idx[i + 2] * d.np] * rA[i + 2];
-          a3 += Hc[(size_t)idx[i + 3] * d.np] * rA[i + 3];
+          a0 += Hc[(size_t)lst[i] * d.np] * rA[i];
+          a1 += Hc[(size_t)lst[i + 1] * d.np] * rA[i + 1];
+          a2 += Hc[(size_t)lst[i + 2] * d.np] * rA[i + 2];
+          a3 += Hc[(size_t)lst[i + 3] * d.np] * rA[i + 3];
         }
-        for (; i < m; ++i) a0 += Hc[(size_t)idx[i] * d.np] * rA[i];
+        for (; i < m; ++i) a0 += Hc[(size_t)lst[i] * d.np] * rA[i];
         x = d.xunc[o + r] - ((a0 + a1) + (a2 + a3));
         if (x > ub + d.bound_tol) dc = 1; else if (x < lb - d.bound_tol) dc = 2;
       } else x = sr == 1 ? ub : lb;
       d.u_out[(size_t)p * d.n + r] = x;                      // final once nothing changes
       dec[r] = dc;
-      if (dc != 255) { ++ninf; rmax = min(rmax, r); }
+      if (dc != 255) { ++ninf; rmin = min(rmin, r); }
     }
     __syncthreads();                                         // dec of the free variables complete
     for (int i = tid; i < m; i += 256) {
-      const int a = idx[i], sa = st[a];
+      const int a = lst[i], sa = st[a];
       const double l = rA[i];
       l1 += fabs(l); lmin = fmin(lmin, fabs(l));
-      if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { dec[a] = 0; ++ninf; rmax = min(rmax, a); }
+      if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { dec[a] = 0; ++ninf; rmin = min(rmin, a); }
     }
     for (int off = 32; off > 0; off >>= 1) {
-      ninf += __shfl_xor(ninf, off); rmax = min(rmax, __shfl_xor(rmax, off));
+      ninf += __shfl_xor(ninf, off); rmin = min(rmin, __shfl_xor(rmin, off));
       l1 += __shfl_xor(l1, off); lmin = fmin(lmin, __shfl_xor(lmin, off));
     }
     __syncthreads();
-    if (lane == 0) { wsum[wave] = ninf; s_i[wave] = rmax; s_d[wave] = l1; s_d[4 + wave] = lmin; }
+    if (lane == 0) { wsum[wave] = ninf; s_i[wave] = rmin; s_d[wave] = l1; s_d[4 + wave] = lmin; }
     __syncthreads();
     ninf = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    rmax = min(min(s_i[0], s_i[1]), min(s_i[2], s_i[3]));
+    rmin = min(min(s_i[0], s_i[1]), min(s_i[2], s_i[3]));
     ++rounds;
+    if (ninf == 0 && fast) {                                 // settled on an updated factor: confirm with a fresh
+      fast = 0; single = 0;                                  // factorisation of the same set (next iteration)
+      __syncthreads();
+      continue;
+    }
     if (ninf == 0) {                                         // settled: certificate as in asm_update_k
       double x1 = 0.0;
       for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
@@ -1168,15 +1267,100 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       return;
     }
     // exchange rule (see asm_update_k)
-    int single = 0;
-    if (ninf < best) { best = ninf; grace = ASM_GRACE; }
+    single = 0;
+    // (the problems that reach the tail have shown that block exchanges do not settle them: a new minimum buys
+    // ASM_TAIL_GRACE block exchanges here, not ASM_GRACE, so most iterations are cheap single exchanges)
+    if (ninf < best) { best = ninf; grace = ASM_TAIL_GRACE; }
     else if (grace > 0) --grace;
     else single = 1;
+    const int dsel = dec[rmin];                              // what the single exchange does: 1 / 2 add at that bound, 0 drop
+    __syncthreads();
     for (int r = tid; r < d.n; r += 256) {
       const unsigned char dc = dec[r];
-      if (dc != 255 && (!single || r == rmax)) st[r] = dc;
+      if (dc != 255 && (!single || r == rmin)) st[r] = dc;
     }
     hi = d.n;
+    if (!single) fast = 0;
+    else if (fast) {
+      // ---- one index enters or leaves the factor (wave 0), or the factor is given up (next iteration rebuilds / refactors)
+      if (wave == 0) {
+        int ok = 1, mm = m;
+        if (dsel != 0) {                                     // add rmin at its upper (1) / lower (2) bound
+          if (mm + 1 >= ASM_FM) ok = 0;
+          else {
+            const double* Hr = d.H + (size_t)rmin * d.np;
+            for (int i = lane; i < mm; i += 64) vv[i] = Hr[al[i]];
+            ASM_FENCE();
+            asm_fwd(Ld, vv, mm, lane);
+            double s2 = 0.0;
+            for (int i = lane; i < mm; i += 64) s2 += vv[i] * vv[i];
+            for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+            const double hd = Hr[rmin], d2 = hd - s2;
+            if (!(d2 > 1e-13 * hd)) ok = 0;
+            else {
+              double* row = Ld + asm_frow(mm);
+              for (int i = lane; i < mm; i += 64) row[i] = vv[i];
+              if (lane == 0) {
+                row[mm] = sqrt(d2); al[mm] = rmin;
+                rhs[mm] = d.xunc[o + rmin] - (dsel == 1 ? ubp[rmin % d.nu] : lbp[rmin % d.nu]);
+              }
+              ++mm;
+            }
+          }
+        } else {                                             // drop rmin: its row leaves, Givens rotations restore the triangle
+          int j = -1;
+          for (int i = lane; i < mm; i += 64) if (al[i] == rmin) j = i;
+          for (int off = 32; off > 0; off >>= 1) j = max(j, __shfl_xor(j, off));
+          if (j < 0) ok = 0;
+          else {
+            // shift the logical arrays (three elements per lane at most: read, then write) ...
+            int av[3]; double hv[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int i = j + lane + 64 * u;
+              av[u] = 0; hv[u] = 0.0;
+              if (i + 1 < mm) { av[u] = al[i + 1]; hv[u] = rhs[i + 1]; }
+            }
+            ASM_FENCE();
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int i = j + lane + 64 * u;
+              if (i + 1 < mm) { al[i] = av[u]; rhs[i] = hv[u]; }
+            }
+            // ... and the rows of the factor: new row i = old row i + 1 (columns 0..i + 1), in ascending order
+            for (int i = j; i + 1 < mm; ++i) {
+              const double* src = Ld + asm_frow(i + 1);
+              double* dst = Ld + asm_frow(i);
+              double tv[3];
+#pragma unroll
+              for (int u = 0; u < 3; ++u) { const int c = lane + 64 * u; tv[u] = c <= i + 1 ? src[c] : 0.0; }
+              ASM_FENCE();
+#pragma unroll
+              for (int u = 0; u < 3; ++u) { const int c = lane + 64 * u; if (c <= i + 1) dst[c] = tv[u]; }
+              ASM_FENCE();
+            }
+            --mm;
+            for (int k = j; k < mm; ++k) {                     // row i >= j now has an entry in column i + 1
+              double* rk = Ld + asm_frow(k);
+              const double a = rk[k], b = rk[k + 1];
+              const double rr = sqrt(a * a + b * b), c = a / rr, s = b / rr;
+              ASM_FENCE();
+              if (lane == 0) { rk[k] = rr; rk[k + 1] = 0.0; }
+              for (int i = k + 1 + lane; i < mm; i += 64) {
+                double* ri = Ld + asm_frow(i);
+                const double pp = ri[k], qq = ri[k + 1];
+                ri[k] = c * pp + s * qq;
+                ri[k + 1] = c * qq - s * pp;
+              }
+              ASM_FENCE();
+            }
+          }
+        }
+        if (lane == 0) { s_m = mm; s_fast = ok; }
+      }
+      __syncthreads();
+      m = s_m; fast = s_fast;
+    }
     __syncthreads();
   }
   if (tid == 0) { d.state[p] = ASM_FALLBACK; d.rounds[p] = rounds; }

@@ -939,7 +939,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // instead of paying eight launches and a read-back per round for them
       EvScope es(h, 4, 0.0);
       hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
-      const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS) * 8 + ((h->n + 15) / 16) * 16;
+      const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_AREA) * 8 + ((h->n + 15) / 16) * 16 + ASM_TAIL_EXTRA;
       hipLaunchKernelGGL(asm_tail_k, dim3(nrun), dim3(256), lds_tail, s, a, a.max_rounds);
       HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(stream_sync(s));
