@@ -26,32 +26,40 @@ using namespace nnmpc;
 
 namespace {
 
-// rows [0, Bp): pass 1 inputs, rows [Bp, 2Bp): pass 2 inputs; columns padded to ldk.
-// Workgroups walk the rows, threads the columns of a row (consecutive lanes read consecutive doubles).
+// rows [0, Bp): pass 1 inputs [x^, (uprev), xs^, us], rows [Bp, 2Bp): pass 2 inputs [xs^, (us), xs^, us] (x^ = x / xscale);
+// columns padded to ldk.  Workgroups walk the SAMPLES: every scaled xs and every us value is computed once and written
+// to all of its places in both rows, segment by segment (no per-element source selection; consecutive lanes read
+// consecutive doubles).  Samples b >= B (batch padding) and the pad columns are zero.
 template <class T>
-__global__ void nn_assemble_k(T* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
+__global__ __launch_bounds__(256) void nn_assemble_k(T* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
                               int with_uprev, const double* __restrict__ x,
                               const double* __restrict__ uprev, const double* __restrict__ xs,
                               const double* __restrict__ us, const float* __restrict__ inv_scale) {
   const int o2 = nx + (with_uprev ? nu : 0);               // first column of the xs block
   const int din = o2 + nx + nu;
-  for (int row = blockIdx.x; row < 2 * Bp; row += gridDim.x) {
-    const int pass = row >= Bp, b = pass ? row - Bp : row;
-    const double* xa = (pass ? xs : x) + (size_t)b * nx;
-    const double* xb = xs + (size_t)b * nx;
-    const double* ua = with_uprev ? (pass ? us : uprev) + (size_t)b * nu : nullptr;
-    const double* ub = us + (size_t)b * nu;
-    T* dst = in + (size_t)row * ldk;
-    for (int k = threadIdx.x; k < ldk; k += blockDim.x) {
-      float f = 0.f;
-      if (b < B && k < din) {
-        if (k < nx) f = (float)xa[k] * inv_scale[k];
-        else if (k < o2) f = (float)ua[k - nx];
-        else if (k < o2 + nx) f = (float)xb[k - o2] * inv_scale[k - o2];
-        else f = (float)ub[k - o2 - nx];
-      }
-      dst[k] = (T)f;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int b = blockIdx.x; b < Bp; b += gridDim.x) {
+    T* d1 = in + (size_t)b * ldk;
+    T* d2 = in + (size_t)(Bp + b) * ldk;
+    if (b >= B) {
+      for (int k = tid; k < ldk; k += nt) { d1[k] = (T)0.f; d2[k] = (T)0.f; }
+      continue;
     }
+    const double* xa = x + (size_t)b * nx;
+    const double* xb = xs + (size_t)b * nx;
+    const double* ub = us + (size_t)b * nu;
+    for (int k = tid; k < nx; k += nt) {
+      const float sc = inv_scale[k];
+      const T xv = (T)((float)xa[k] * sc), sv = (T)((float)xb[k] * sc);
+      d1[k] = xv; d1[o2 + k] = sv;
+      d2[k] = sv; d2[o2 + k] = sv;
+    }
+    for (int k = tid; k < nu; k += nt) {
+      const T uv = (T)(float)ub[k];
+      d1[o2 + nx + k] = uv; d2[o2 + nx + k] = uv;
+      if (with_uprev) { d1[nx + k] = (T)(float)uprev[(size_t)b * nu + k]; d2[nx + k] = uv; }
+    }
+    for (int k = din + tid; k < ldk; k += nt) { d1[k] = (T)0.f; d2[k] = (T)0.f; }
   }
 }
 
@@ -269,10 +277,10 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       dup = h->with_uprev ? uprev + (size_t)b0 * nu : nullptr; du = u + (size_t)b0 * nu;
     }
     if (h->use_bf16)
-      hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(8192), dim3(h->kpad[0] % 192 == 0 ? 192 : 256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
+      hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(8192), dim3(256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
                          h->kpad[0], Bp, nb, nx, nu, h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     else
-      hipLaunchKernelGGL(nn_assemble_k<float>, dim3(8192), dim3(h->kpad[0] % 192 == 0 ? 192 : 256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
+      hipLaunchKernelGGL(nn_assemble_k<float>, dim3(8192), dim3(256), 0, s, h->act[0], h->kpad[0], Bp, nb, nx, nu,
                          h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     hipEventRecord(h->eg[3 * nsub], s);
     int cur = 0;
