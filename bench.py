@@ -190,7 +190,7 @@ def main():
     from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
     from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
 
-    B = args.batch or (65536 if args.workload == "cdu" else 131072)
+    B = args.batch or (100000 if args.workload == "cdu" else 131072)   # cdu: BASELINE.json configs[2], "100k sampled x0, 1 MI355X"
     slots = args.slots or (1024 if args.workload == "cdu" else 8192)
     pl = synthetic.plant(args.workload, seed=0)
     P, tq, nu = build_regulator_matrices(pl)
@@ -281,14 +281,19 @@ def main():
         if st["asm_solved"]:
             # shared-inverse active-set pass: two kernels carry the time; the one with the larger
             # hipEvent share is reported as `roofline`, the other as `roofline_secondary`
+            # mean HBM bytes per launch of the kernels from the PMC passes of profiles/r01j_pmc_asm.json (scripts/pmc_hbm.py,
+            # same command, B = 100000); null at other batch sizes
+            pmc_asm, pmc_file = {}, os.path.join(ROOT, "profiles", "r01j_pmc_asm.json")
+            if args.workload == "cdu" and B == 100000 and os.path.exists(pmc_file):
+                for k, v in json.load(open(pmc_file))["kernels"].items():
+                    pmc_asm[k.split("::")[-1].split("<")[0]] = v["hbm_bytes_per_launch"]
             gach = st["asm_gemm_flops"] / (st["asm_gemm_ms"] * 1e-3) / 1e12
             gemm = {"kernel": "gemm_nt_f64_128_k (x_unc = x0 Kunc', XH = LAM Pinv inside the column window, one full-width pass; "
                               "the f32 rounds' XH32 = LAM32 Pinv32 on gemm_nt_f32_kdyn_k is in the same time and flop count)",
                     "bound": "mfma", "achieved": gach, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": gach / FP64_PEAK_TFLOPS,
-                    # mean HBM bytes per launch from the PMC passes of profiles/r01h_pmc_asm.json (B = 65536)
-                    "traffic": 7.9e8 if (args.workload == "cdu" and B == 65536) else None,
-                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01h_pmc_asm.json)",
+                    "traffic": pmc_asm.get("gemm_nt_f64_128_k"),
+                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01j_pmc_asm.json)",
                     "launches": st["asm_gemm_launches"], "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]),
                     "algorithmic_flops": "2 * (columns evaluated) * (own last active bound + 1) per running problem and round (columns = window past the round's last active bound) + x_unc = x0 Kunc' + one full-width pass per problem",
                     "time_share": st["asm_gemm_ms"] / st["total_ms"]}
@@ -297,10 +302,10 @@ def main():
                              "wave per problem, tiles in the MFMA accumulators; f32 rounds until the set settles, then fp64)",
                    "bound": "mfma", "achieved": lach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": lach / FP64_PEAK_TFLOPS,
-                   # HBM bytes per launch from the PMC passes of profiles/r01h_pmc_asm.json (B = 65536): the gathered
-                   # Pinv blocks (algorithmic_GBps below) come from L2 / Infinity Cache, not from HBM
-                   "traffic": 5.8e8 if (args.workload == "cdu" and B == 65536) else None,
-                   "traffic_unit": "HBM bytes per launch of the f32 kernel, 1.1e8 for the fp64 one (profiles/r01h_pmc_asm.json)",
+                   # the gathered Pinv blocks (algorithmic_GBps below) come from L2 / Infinity Cache, not from HBM
+                   "traffic": pmc_asm.get("asm_lambda_reg32_k"),
+                   "traffic_fp64_kernel": pmc_asm.get("asm_lambda_reg_k"),
+                   "traffic_unit": "HBM bytes per launch of asm_lambda_reg32_k / asm_lambda_reg_k (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01j_pmc_asm.json)",
                    "algorithmic_flops": "m^3/3 + 2 m^2 per problem and round, m = size of its active set (f32 and fp64 rounds "
                                         "alike; priced against the fp64 MFMA peak)",
                    "algorithmic_GBps": st["asm_lambda_bytes"] / (st["asm_lambda_ms"] * 1e-3) / 1e9,
