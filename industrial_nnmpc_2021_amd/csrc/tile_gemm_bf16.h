@@ -167,7 +167,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WBM = 256, WBN = 208, WNT = 7;               // WNT: column tiles of the wn = 0 waves (wn = 1: 6)
 constexpr int W_STAGE = (WBM + 256) * 64;                  // bf16 elements per stage (A, then B padded to 256 rows: staging writes need no branch)
 constexpr int W_LDS_BYTES = 2 * W_STAGE * 2 + 1024;        // two stages + the workgroup's bias values
-constexpr int W_BPIECES = WBN * 8;                         // 16-byte pieces of a B chunk
 
 template <bool RELU, bool BIAS>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ C, int ldc,
