@@ -934,9 +934,10 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
     kprev = cnt[3];
     if (nrun == 0) break;
-    if (nrun <= std::min(h->asm_pool, 256) && rounds >= 12) {
+    if (nrun <= std::min(h->asm_pool, 256) && rounds >= 6) {
       // the tail: a handful of stragglers (the bulk settles in 5-8 rounds) -- finish them on the device (asm_tail_k)
-      // instead of paying eight launches and a read-back per round for them
+      // instead of paying eight launches and a read-back per round for them.  From round 6 on (12 before: at 100 000
+      // problems per call the rounds 7..12 were launches for a few dozen problems, 5 % of the step)
       EvScope es(h, 4, 0.0);
       hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
       const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_AREA) * 8 + ((h->n + 15) / 16) * 16 + ASM_TAIL_EXTRA;
