@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: condensed-QP solves/sec of the CDU offline-datagen hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cdu|cstrs] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--workload cdu|cstrs|nn|chains] [--batch B]
 
-One "step" = one pass of the hot path (q = tq x0 -> batched PDIP + polish ->
-first moves) over one batch of B synthetic CDU-size problems per GPU
-(Nx=252, Nu=32, N=140 -> n=4480 variables, m=8960 box rows; reference sizes
-cdu_parameters.py:99-102), inputs already resident in HBM.  N > 1: one process
-per GPU (torch.distributed, backend nccl = RCCL), the sample batch is sharded
-(weak scaling: B per GPU), no collective during the solves and ONE gather of
-the first moves over xGMI at the end of every step.
+One "step" = one pass of the hot path (x_unc = Kunc x0 -> shared-inverse active-set rounds -> certified u*, active
+sets, status -> first moves) over one batch of B synthetic CDU-size problems per GPU (Nx=252, Nu=32, N=140 -> n=4480
+variables, m=8960 box rows; reference sizes cdu_parameters.py:99-102), inputs already resident in HBM.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+N > 1: one process per GPU.  Started under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment)
+the process is one rank; started plainly with --gpus N > 1 it launches its own N ranks as child processes before
+anything touches the GPU.  The sample batch is sharded (weak scaling: B per GPU; 125 000 per GPU at N = 8 =
+BASELINE.json's "1M sampled x0 over 8 GPUs"), no collective during the solves and ONE RCCL gather of the first moves
+over xGMI at the end of every step -- through the library (nnmpc_comm_*); this file binds nothing but libnnmpc_hip.so.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").  At N = 1 the default run also measures, outside the
+headline's timed region, the other single-GPU configurations of BASELINE.json (`configs`), the active-fraction sweep,
+the lock-step chain workload, the PDIP path, the PCIe-inclusive rate, the parity checks and the CPU baseline.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,41 +32,507 @@ sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X dense f32 matrix/vector peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6   # f64 vector = matrix peak (half the f32 rate; v_mfma_f64_16x16x4_f64)
+BF16_PEAK_TFLOPS = 2500.0
 
 
-def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s=30.0, workload="cdu"):
-    """Restated reference CPU path (oracle.qp.coneqp_l: cvxopt-style dense-G PDIP,
-    fp64, one problem at a time) timed on this host.  Bounded sample."""
-    from oracle import qp as oqp
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch: N ranks as fresh child processes (nothing has touched the GPU in this process yet)
+def launch_ranks(argv, n):
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def csrc_sha():
+    """Hash of the kernel sources: a stored PMC profile is only quoted for the build it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "industrial_nnmpc_2021_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of a kernel from profiles/pmc_hbm_<name>.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes,
+    scripts/pmc_hbm.py, gfx950 corrections applied) when that profile was taken on THIS build of the kernels; else {}."""
+    f = os.path.join(ROOT, "profiles", f"pmc_hbm_{name}.json")
+    if not os.path.exists(f):
+        return {}, "no PMC profile for this workload"
+    d = json.load(open(f))
+    if d.get("csrc_sha") != csrc_sha():
+        return {}, f"stale: {os.path.basename(f)} was taken on kernel sources {d.get('csrc_sha')}, this build is {csrc_sha()}"
+    out = {}
+    for k, v in d["kernels"].items():
+        out[k.split("::")[-1].split("<")[0].split("(")[0].strip()] = v["hbm_bytes_per_launch"]
+    return out, f"profiles/{os.path.basename(f)} (FETCH_SIZE x2 + WRITE_SIZE, same kernel sources)"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    blas = "unknown"
     try:
         from threadpoolctl import threadpool_info
+        blas = ", ".join(sorted({f"{i.get('internal_api')} {i.get('version')}" for i in threadpool_info()
+                                 if i.get("user_api") == "blas"}))
+    except Exception:
+        pass
+    return model, blas
+
+
+def _cpu_worker(args):
+    """One process of the reference's parallel model (lib/linearMPC.py:817-820): 1 BLAS thread, its own problems."""
+    (P, tq, nu, N, x0, lb, ub, budget_s) = args
+    from threadpoolctl import threadpool_limits
+    from oracle import qp as oqp
+    done, t0, its = 0, time.time(), []
+    with threadpool_limits(limits=1):
+        for b in range(x0.shape[0]):
+            G, h = oqp.box_as_Gh(nu, N, lb[b], ub[b])
+            info = {}
+            oqp.coneqp_l(P, tq @ x0[b], G, h, info=info)
+            its.append(info["iterations"]); done += 1
+            if time.time() - t0 > budget_s:
+                break
+    return done, time.time() - t0, its
+
+
+def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
+    """Restated reference CPU path (oracle.qp.coneqp_l: cvxopt-style dense-G PDIP, fp64, one problem at a time)
+    timed on this host's cores.  Bounded sample.  Modes: (a) one process, all cores through
+    the BLAS threads; (b) one process, ONE BLAS thread; (c) nproc independent single-thread processes (the reference's
+    own parallel model).  (b), (c) at the CDU size only with --cpu-baseline full (a single-thread CDU solve takes
+    about a minute: outside the default run's budget)."""
+    from oracle import qp as oqp
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
     except Exception:
-        threads = os.cpu_count() or 1
+        threads, threadpool_limits = os.cpu_count() or 1, None
     n = P.shape[0]
+    model, blas = cpu_info()
     done, t0, its = 0, time.time(), []
     for b in range(x0.shape[0]):
         G, h = oqp.box_as_Gh(nu, N, lb[b], ub[b])
         info = {}
         oqp.coneqp_l(P, tq @ x0[b], G, h, info=info)
-        its.append(info["iterations"])
-        done += 1
+        its.append(info["iterations"]); done += 1
         if time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
-    return {"value": done / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
-            "sample": f"{done} problem(s) of the same seeded batch, n={n}, m={2 * n}, dense G, "
-                      f"cvxopt-default tolerances, mean {np.mean(its):.1f} PDIP iterations, {dt:.1f} s",
-            "paper_reference": ("CVXOPT 35 s/solve mean, 47 s worst on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"
-                                if workload == "cdu" else
-                                "CVXOPT 8-13 s/solve on a 2.4 GHz cluster CPU at the paper's N=450 (n=2700; the code ships N=90, n=540) (KumarRawlingsWright2021 p.7)")}
+    res = {"value": done / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
+           "sample": f"{done} problem(s) of the same seeded batch, n={n}, m={2 * n}, dense G, cvxopt-default tolerances, "
+                     f"mean {np.mean(its):.1f} PDIP iterations, {dt:.1f} s, one process with {threads} BLAS threads",
+           "cpu_model": model, "blas": blas, "host_cores": os.cpu_count(),
+           "paper_reference": ("CVXOPT 35 s/solve mean, 47 s worst on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"
+                               if workload == "cdu" else
+                               "CVXOPT 8-13 s/solve on a 2.4 GHz cluster CPU at the paper's N=450 (n=2700; the code ships N=90, n=540) (KumarRawlingsWright2021 p.7)")}
+    if (workload != "cdu" or full) and threadpool_limits is not None:
+        k = 4 if workload == "cdu" else 32
+        d1, t1, i1 = _cpu_worker((P, tq, nu, N, x0[:k], lb[:k], ub[:k], 1e9 if full else budget_s))
+        res["one_thread"] = {"value": d1 / t1, "unit": "solves/s", "cores": 1,
+                             "sample": f"{d1} problem(s), one process, 1 BLAS thread, {t1:.1f} s"}
+        import multiprocessing as mp
+        nproc = min(os.cpu_count() or 1, 16 if workload == "cdu" else 64)
+        per = 1 if workload == "cdu" else 8
+        jobs = [(P, tq, nu, N, x0[i * per:(i + 1) * per], lb[i * per:(i + 1) * per], ub[i * per:(i + 1) * per], 1e9)
+                for i in range(nproc) if (i + 1) * per <= x0.shape[0]]
+        t2 = time.time()
+        with mp.get_context("fork").Pool(len(jobs)) as pool:
+            rr = pool.map(_cpu_worker, jobs)
+        t2 = time.time() - t2
+        res["nproc_processes"] = {"value": sum(r[0] for r in rr) / t2, "unit": "solves/s", "cores": len(jobs),
+                                  "sample": f"{sum(r[0] for r in rr)} problems over {len(jobs)} independent processes "
+                                            f"(1 BLAS thread each; the reference's parallel model, lib/linearMPC.py:817-820), {t2:.1f} s wall"}
+    return res
 
 
-def bench_nn(args, torch, dev, rank, world, dist):
+# ------------------------------------------------------------------------------------------------------------------
+class Ctx:
+    """One rank: its device, its communicator (None at world 1 unless NNMPC_FORCE_DIST=1)."""
+
+    def __init__(self, args):
+        from industrial_nnmpc_2021_amd import _lib, distributed
+        self.lib = _lib
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        if _lib.device_count() <= self.local_rank:
+            raise SystemExit("bench.py needs a GPU per rank (the HIP path has no CPU fallback)")
+        _lib.set_device(self.local_rank)
+        self.comm = None
+        if self.world > 1 or os.environ.get("NNMPC_FORCE_DIST") == "1":
+            self.comm = distributed.Comm(self.rank, self.world)
+
+    def sync(self):
+        if self.comm is not None:
+            self.comm.barrier()
+        else:
+            self.lib.synchronize()
+
+    def max_over_ranks(self, v):
+        return self.comm.allreduce_max(v) if self.comm is not None else v
+
+
+def make_problem(workload, seed=0):
+    from industrial_nnmpc_2021_amd import synthetic
+    from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
+    pl = synthetic.plant(workload, seed=seed)
+    P, tq, nu = build_regulator_matrices(pl)
+    return pl, P, tq, nu
+
+
+def make_samples(pl, B, seed, sx):
+    from industrial_nnmpc_2021_amd import synthetic
+    s = synthetic.samples(pl, B, seed=seed, sx=sx)
+    x0 = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), axis=1)
+    return x0, np.ascontiguousarray(pl["ulb"].T - s["us"]), np.ascontiguousarray(pl["uub"].T - s["us"]), s["us"]
+
+
+class QpBuffers:
+    """HBM-resident inputs and outputs of one batch (owned through the library: _lib.DeviceArray)."""
+
+    def __init__(self, lib, qp, B, nu, n):
+        D = lib.DeviceArray
+        self.x0, self.lb, self.ub, self.us = D((B, qp.n_aug), np.float64), D((B, nu), np.float64), D((B, nu), np.float64), D((B, nu), np.float64)
+        self.u, self.act = D((B, n), np.float64), D((B, qp.words), np.uint32)
+        self.status, self.iters, self.first = D((B,), np.int32), D((B, 2), np.int32), D((B, nu), np.float64)
+        self.B = B
+
+    def upload(self, x0, lb, ub, us):
+        self.x0.upload(x0); self.lb.upload(lb); self.ub.upload(ub); self.us.upload(us)
+
+    def free(self):
+        for a in (self.x0, self.lb, self.ub, self.us, self.u, self.act, self.status, self.iters, self.first):
+            a.free()
+
+
+def lambda_rooflines(st, traffic):
+    """The two instances of the multiplier kernel, each priced against the peak of its OWN number type."""
+    f32 = st["asm_lambda32_flops"]
+    f64 = st["asm_lambda_flops"] - f32
+    out = []
+    for name, fl, ms, launches, peak, dt in (
+            ("asm_lambda_reg32_k", f32, st["asm_lambda32_ms"], st["asm_lambda32_launches"], FP32_PEAK_TFLOPS, "f32"),
+            ("asm_lambda_reg_k", f64, st["asm_lambda64_ms"], st["asm_lambda64_launches"], FP64_PEAK_TFLOPS, "f64")):
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out.append({"kernel": f"{name} (|A| x |A| Cholesky + two substitutions per problem: one wave per problem, tiles in the MFMA "
+                              f"accumulators, v_mfma_{dt}_16x16x4_{dt})", "dtype": dt, "bound": "mfma", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic.get(name),
+                    "launches": int(launches), "avg_launch_ms": ms / max(1, launches), "time_share": ms / st["total_ms"],
+                    "algorithmic_flops": "m^3/3 + 2 m^2 per problem and round, m = size of its active set; the classes beyond 144 bounds "
+                                         "(side-stream kernels asm_lambda_reg32b_k / reg2_k / tile_k<1>) are in the flop count of their "
+                                         "number type but not in this kernel's time: `achieved` is an upper bound by their share (<= 3 %)"})
+    return out
+
+
+def bench_qp(ctx, workload, B, steps, warmup, sx, method="auto", slots=0, seed0=1000, want_buffers=False):
+    """K timed steps of the regulator QP batch on this rank (+ the gather at world > 1).  Returns (result dict, handles)."""
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    lib = ctx.lib
+    pl, P, tq, nu = make_problem(workload)
+    n, n_aug, N = P.shape[0], tq.shape[1], pl["N"]
+    slots = slots or (1024 if workload == "cdu" else 8192)
+    qp = BatchedBoxQP(P, tq, nu, max_batch=min(slots, B), method=method)
+    x0_h, lb_h, ub_h, us_h = make_samples(pl, B, seed0 + ctx.rank, sx)     # every rank draws its own shard of the stream
+    buf = QpBuffers(lib, qp, B, nu, n)
+    buf.upload(x0_h, lb_h, ub_h, us_h)
+    gathered = lib.DeviceArray((ctx.world * B, nu), np.float64) if (ctx.comm is not None and ctx.rank == 0) else None
+    rows = [B] * ctx.world
+
+    def step():
+        qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.u, buf.act, buf.status, buf.iters)
+        # get_control_sequence adds us back (:689); ut = useq[0:Nu] (:856)
+        lib.check(lib.load().nnmpc_qp_first_moves(buf.u.data_ptr(), n, buf.us.data_ptr(), B, nu, buf.first.data_ptr()), "nnmpc_qp_first_moves")
+        if ctx.comm is not None:
+            ctx.comm.gather_rows(buf.first, rows, nu, gathered, root=0)   # the single RCCL gather over xGMI
+
+    for _ in range(warmup):
+        step()
+    qp.set_profiling(True)
+    qp.stats(reset=True)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    dt_local = time.perf_counter() - t0
+    dt = ctx.max_over_ranks(dt_local)
+    st = qp.stats()
+    qp.set_profiling(False)
+    status_h, iters_h = buf.status.to_host(), buf.iters.to_host()
+    res = {"value": ctx.world * B * steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / steps,
+           "per_rank_solves_per_s_this_rank": B * steps / dt_local,
+           "solver": {"status_hist": np.bincount(status_h, minlength=3).tolist(),
+                      "solved_by_active_set_pass": int(st["asm_solved"]), "active_set_rounds_per_step": st["asm_rounds"] / steps,
+                      "solved_by_pdip_path": int(st["problems"] - st["asm_solved"]),
+                      "mean_pdip_iters": float(iters_h[:, 0].mean()), "mean_factorizations": float(iters_h[:, 1].mean()),
+                      "mean_active_bounds": float(np.unpackbits(buf.act.to_host(min(B, 4096)).view(np.uint8), axis=1).sum(axis=1).mean()),
+                      "bounds_per_problem": 2 * n}}
+    if st["asm_solved"]:
+        traffic, tnote = pmc_traffic(f"{workload}_b{B}")
+        gach = st["asm_gemm_flops"] / (st["asm_gemm_ms"] * 1e-3) / 1e12
+        gemm = {"kernel": "gemm_nt_f64_128_k (x_unc = x0 Kunc', XH = LAM Pinv inside the column window, one full-width pass; the f32 "
+                          "rounds' XH32 = LAM32 Pinv32 on gemm_nt_f32_kdyn_k is in the same time and flop count)", "dtype": "f64",
+                "bound": "mfma", "achieved": gach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gach / FP64_PEAK_TFLOPS,
+                "traffic": traffic.get("gemm_nt_f64_128_k"), "launches": int(st["asm_gemm_launches"]),
+                "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]), "time_share": st["asm_gemm_ms"] / st["total_ms"],
+                "algorithmic_flops": "2 * (columns evaluated) * (own last active bound + 1) per running problem and round + x_unc = x0 Kunc' "
+                                     "+ one full-width pass per problem"}
+        cands = lambda_rooflines(st, traffic) + [gemm]
+        cands.sort(key=lambda r: -r["time_share"])
+        res["roofline"], res["roofline_secondary"], res["roofline_third"] = cands[0], cands[1], cands[2]
+        res["roofline"]["traffic_unit"] = "HBM bytes per launch; " + tnote
+        res["time_shares"] = {"multiplier_kernels_both_streams": st["asm_lambda_ms"] / st["total_ms"], "gemms": st["asm_gemm_ms"] / st["total_ms"],
+                              "set_bookkeeping_kernels": st["asm_update_ms"] / st["total_ms"]}
+        res["solver"]["checked_with_P_itself"] = int(st["asm_full_checks"])
+        res["solver"]["inverse_check"] = {"max_abs_P_Pinv_minus_I": st["asm_e2max"], "max_abs_P_Kunc_plus_tq": st["asm_e1max"]}
+        res["dtype"] = "f64"
+    else:
+        res["roofline"] = panel_roofline(st, n, workload)
+        res["dtype"] = "f32"
+    handles = dict(qp=qp, buf=buf, pl=pl, P=P, tq=tq, nu=nu, N=N, n=n, host=(x0_h, lb_h, ub_h, us_h))
+    if not want_buffers:
+        qp.close(); buf.free()
+        handles = None
+    return res, handles
+
+
+def panel_roofline(stx, n, workload):
+    fl, ms = stx["panel_flops"], stx["panel_ms"]
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic, tnote = pmc_traffic(f"{workload}_pdip")
+    return {"kernel": "chol_panel_k", "dtype": "f32", "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic.get("chol_panel_k"), "traffic_unit": "HBM bytes per launch; " + tnote,
+            "launches": int(stx["panel_launches"]), "avg_launch_ms": ms / max(1, stx["panel_launches"]),
+            "time_share": {"chol_panel": ms / stx["total_ms"], "chol_diag": stx["diag_ms"] / stx["total_ms"], "trsv": stx["trsv_ms"] / stx["total_ms"]},
+            # whole-solve rate in the survey's dense-PDIP flop model: factorisations * n^3/3
+            "cholesky_flops_over_solve_time_TFLOPs": stx["factorizations"] * n ** 3 / 3 / (stx["total_ms"] * 1e-3) / 1e12}
+
+
+def parity_leg(h, k_oracle, k_kkt):
+    """Independent checks of the batch just solved: (a) k_kkt random rows through the fp64 KKT conditions evaluated in
+    numpy, (b) k_oracle rows -- the largest active sets, the rows that needed the most rounds' worth of work are among
+    the largest, and random ones -- against the exact-optimum oracle."""
+    from oracle import qp as oqp
+    buf, P, tq, nu, N, n = h["buf"], h["P"], h["tq"], h["nu"], h["N"], h["n"]
+    x0_h, lb_h, ub_h, _ = h["host"]
+    B = buf.B
+    Ps = np.tril(P) + np.tril(P, -1).T
+    rng = np.random.default_rng(5)
+    act_all = buf.act.to_host()
+    nact = np.unpackbits(act_all.view(np.uint8), axis=1).sum(axis=1)
+    big = np.argsort(-nact)[:k_oracle // 2]
+    rows_o = np.unique(np.concatenate((big, rng.choice(B, k_oracle, replace=False))))[:max(k_oracle, 1)]
+    rows_k = np.unique(np.concatenate((rows_o, rng.choice(B, min(B, k_kkt), replace=False))))
+    # pull only the rows needed (B x n doubles is 3.6 GB at the CDU size)
+    U = np.stack([np.frombuffer(_row(buf.u, r, n * 8), np.float64) for r in rows_k])
+    bits = np.unpackbits(act_all[rows_k].view(np.uint8), axis=1, bitorder="little")[:, :2 * n].astype(bool)
+    kk, cc = np.arange(n) // nu, np.arange(n) % nu
+    au, al = bits[:, kk * 2 * nu + cc], bits[:, kk * 2 * nu + nu + cc]
+    G = U @ Ps + x0_h[rows_k] @ tq.T
+    LB, UB = np.tile(lb_h[rows_k], (1, N)), np.tile(ub_h[rows_k], (1, N))
+    scale = np.maximum(1.0, np.abs(x0_h[rows_k] @ tq.T).max(axis=1, keepdims=True))
+    free = ~(au | al)
+    kkt = {"rows": int(rows_k.size),
+           "max_stationarity_residual_rel": float((np.abs(np.where(free, G, 0)) / scale).max()),
+           "max_bound_violation": float(max((U - UB).max(), (LB - U).max(), 0.0)),
+           "active_rows_exactly_on_their_bound": bool(np.abs(np.where(au, U - UB, 0)).max() == 0 and np.abs(np.where(al, U - LB, 0)).max() == 0),
+           "wrong_sign_multipliers": int((np.where(au, -G, 1) <= 0).sum() + (np.where(al, G, 1) <= 0).sum())}
+    errs, ham, sizes = [], 0, []
+    pos = {r: i for i, r in enumerate(rows_k)}
+    for r in rows_o:
+        info = {"nu": nu}
+        xe = oqp.solve_exact_box(Ps, tq @ x0_h[r], np.tile(lb_h[r], N), np.tile(ub_h[r], N), info=info)
+        ref = np.zeros(2 * n, bool)
+        ref[info["active"]] = True
+        errs.append(float(np.abs(U[pos[r]] - xe).max() / max(1.0, np.abs(xe).max())))
+        ham += int((bits[pos[r]] != ref).sum())
+        sizes.append(int(ref.sum()))
+    return {"checked": int(rows_o.size), "max_rel_err_vs_fp64_oracle": max(errs) if errs else None, "active_set_hamming": ham,
+            "oracle_rows_active_set_sizes": {"min": min(sizes), "max": max(sizes)} if sizes else None,
+            "largest_active_set_in_batch": int(nact.max()), "kkt_check": kkt}
+
+
+def _row(dev, r, nbytes):
+    import ctypes as C
+    from industrial_nnmpc_2021_amd import _lib
+    out = (C.c_char * nbytes)()
+    _lib.check(_lib.load().nnmpc_memcpy_d2h(out, dev.row_ptr(r), nbytes), "nnmpc_memcpy_d2h")
+    return bytes(out)
+
+
+def pdip_leg(ctx, h, Bp):
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    lib = ctx.lib
+    buf, n, nu = h["buf"], h["n"], h["nu"]
+    qp2 = BatchedBoxQP(h["P"], h["tq"], nu, max_batch=min(1024, Bp), method="pdip")
+    b2 = QpBuffers(lib, qp2, Bp, nu, n)
+    qp2.solve_batch_device(min(Bp, 256), buf.x0, buf.lb, buf.ub, b2.u, b2.act, b2.status, b2.iters)      # warm-up
+    qp2.set_profiling(True); qp2.stats(reset=True)
+    lib.synchronize(); t1 = time.perf_counter()
+    qp2.solve_batch_device(Bp, buf.x0, buf.lb, buf.ub, b2.u, b2.act, b2.status, b2.iters)
+    lib.synchronize(); dt2 = time.perf_counter() - t1
+    s2 = qp2.stats()
+    it2 = b2.iters.to_host()
+    k = min(Bp, 256)
+    du = float(np.abs(b2.u.to_host(k) - buf.u.to_host(k)).max())
+    out = {"value": Bp / dt2, "unit": "solves/s", "batch": Bp, "dtype": "f32 (+f64 refinement)",
+           "status_hist": np.bincount(b2.status.to_host(), minlength=3).tolist(),
+           "mean_pdip_iters": float(it2[:, 0].mean()), "mean_factorizations": float(it2[:, 1].mean()),
+           "max_abs_diff_vs_active_set_pass": du, "compared_rows": k,
+           "active_sets_equal": bool(np.array_equal(b2.act.to_host(), buf.act.to_host(Bp))),
+           "roofline": panel_roofline(s2, n, "cdu")}
+    qp2.close(); b2.free()
+    return out
+
+
+def host_io_leg(ctx, h):
+    """The same batch with host buffers either side (never `value`): pinned host memory -> HBM over PCIe, the solve, first
+    moves (what simulate_offline keeps, lib/linearMPC.py:856) or full sequences back to the host."""
+    import ctypes as C
+    lib = ctx.lib
+    L = lib.load()
+    qp, buf, n, nu = h["qp"], h["buf"], h["n"], h["nu"]
+    x0_h, lb_h, ub_h, us_h = h["host"]
+    B = buf.B
+
+    def pinned(a):
+        p = C.c_void_p()
+        lib.check(L.nnmpc_host_alloc_pinned(C.byref(p), a.nbytes), "nnmpc_host_alloc_pinned")
+        v = np.frombuffer((C.c_char * a.nbytes).from_address(p.value), dtype=a.dtype).reshape(a.shape)
+        v[...] = a
+        return p, v
+    pins = [pinned(a) for a in (x0_h, lb_h, ub_h)]
+    pf, vf = pinned(np.empty((B, nu)))
+    pu, vu = pinned(np.empty((B, n)))
+    hio = {}
+    for name, full in (("first_move", False), ("full_sequence", True)):
+        best = None
+        for _ in range(2):
+            lib.synchronize(); t1 = time.perf_counter()
+            for (p, v), d in zip(pins, (buf.x0, buf.lb, buf.ub)):
+                lib.check(L.nnmpc_memcpy_h2d(C.c_void_p(d.data_ptr()), p, v.nbytes), "h2d")
+            qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.first if not full else buf.u, buf.act, buf.status, buf.iters,
+                                  first_move_only=not full)
+            if full:
+                lib.check(L.nnmpc_memcpy_d2h(pu, C.c_void_p(buf.u.data_ptr()), vu.nbytes), "d2h")
+            else:
+                lib.check(L.nnmpc_memcpy_d2h(pf, C.c_void_p(buf.first.data_ptr()), vf.nbytes), "d2h")
+            lib.synchronize(); d_ = time.perf_counter() - t1
+            best = d_ if best is None else min(best, d_)
+        hio[name + "_solves_per_s"] = B / best
+        hio[name + "_ms"] = 1e3 * best
+    hio["bytes_in"] = int(sum(v.nbytes for _, v in pins))
+    hio["bytes_out_first_move"] = B * nu * 8
+    hio["bytes_out_full_sequence"] = B * n * 8
+    hio["note"] = ("PCIe-inclusive: pinned host buffers -> HBM, solve, results -> pinned host buffers; best of 2; the first-move run uses "
+                   "NNMPC_OUT_FIRST_MOVE (u* is not written out in full)")
+    for p, _ in pins + [(pf, vf), (pu, vu)]:
+        L.nnmpc_host_free_pinned(p)
+    return hio
+
+
+def first_move_leg(ctx, h, steps):
+    """The headline batch again with NNMPC_OUT_FIRST_MOVE: every problem solved and certified as before, only
+    useq[0:Nu] leaves the solver (all the offline simulation keeps, lib/linearMPC.py:856).  Not `value`."""
+    lib = ctx.lib
+    qp, buf = h["qp"], h["buf"]
+    B = buf.B
+    qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.first, buf.act, buf.status, buf.iters, first_move_only=True)
+    lib.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.first, buf.act, buf.status, buf.iters, first_move_only=True)
+    lib.synchronize(); dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / steps,
+            "status_hist": np.bincount(buf.status.to_host(), minlength=3).tolist()}
+
+
+def sweep_leg(ctx, h, sxs, steps):
+    """The same plant and batch size at other state spreads: 0.5-5 % of the 8960 bounds active."""
+    lib = ctx.lib
+    qp, buf, n, nu, pl = h["qp"], h["buf"], h["n"], h["nu"], h["pl"]
+    B = buf.B
+    out = {}
+    for sx in sxs:
+        x0, lb, ub, us = make_samples(pl, B, 2000 + int(10 * sx), sx)
+        buf.upload(x0, lb, ub, us)
+        qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.u, buf.act, buf.status, buf.iters)
+        qp.stats(reset=True)
+        lib.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.u, buf.act, buf.status, buf.iters)
+        lib.synchronize(); dt = time.perf_counter() - t0
+        st = qp.stats()
+        nact = np.unpackbits(buf.act.to_host(min(B, 8192)).view(np.uint8), axis=1).sum(axis=1)
+        out[f"sx={sx:g}"] = {"value": B * steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / steps,
+                             "mean_active_bounds": float(nact.mean()), "max_active_bounds": int(nact.max()),
+                             "active_fraction": float(nact.mean() / (2 * n)),
+                             "status_hist": np.bincount(buf.status.to_host(), minlength=3).tolist(),
+                             "rounds_per_step": st["asm_rounds"] / steps, "solved_by_pdip_path": int(st["problems"] - st["asm_solved"])}
+    buf.upload(*h["host"])
+    return out
+
+
+def chains_leg(ctx, workload, nc, T, h=None):
+    """Lock-step closed-loop chains (simulate_offline, lib/linearMPC.py:845-866) for nc chains x T steps, device resident:
+    149 chains is the reference's CDU task count (cdu_parameters.py:211).  Target pairs are drawn (piecewise constant),
+    not solved here: the leg times regulator solve + model step + warm-start shift per step."""
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    from industrial_nnmpc_2021_amd.chain import DeviceChains
+    pl, P, tq, nu = (h["pl"], h["P"], h["tq"], h["nu"]) if h else make_problem(workload)
+    Nx = pl["A"].shape[0]
+    rng = np.random.default_rng(77)
+    Nd = 5
+    Bd = rng.standard_normal((Nx, Nd)) / np.sqrt(Nx)
+    qp = BatchedBoxQP(P, tq, nu, max_batch=max(128, nc), seg_max=max(128, nc))
+    ch = DeviceChains(qp, nc, pl["A"], pl["B"], Bd, pl["ulb"], pl["uub"], np.zeros(Nx), np.zeros(nu))
+    hold = max(2, T // 3)
+    Us = np.repeat(rng.uniform(-0.5, 0.5, ((T + hold - 1) // hold, nc, nu)), hold, axis=0)[:T]
+    Xs = np.repeat(0.5 * rng.standard_normal(((T + hold - 1) // hold, nc, Nx)), hold, axis=0)[:T]
+    D = np.repeat(rng.standard_normal(((T + hold - 1) // hold, nc, Nd)), hold, axis=0)[:T]
+    ch.run(Xs[:2], Us[:2], D[:2])                      # warm-up
+    ch.reset()
+    t0 = time.perf_counter()
+    rec = ch.run(Xs, Us, D, warm_start=True)
+    dt = time.perf_counter() - t0
+    dev_ms, solve_ms = ch.last_ms()
+    out = {"value": nc * T / dt, "unit": "chain-steps/s (one regulator QP + model step each)", "chains": nc, "steps": T,
+           "ms_per_step": 1e3 * dt / T, "device_ms_per_step": dev_ms / T, "solve_ms_per_step": solve_ms / T,
+           "status_hist": np.bincount(rec["status"].ravel(), minlength=3).tolist(),
+           "max_abs_u": float(np.abs(rec["u"]).max()),
+           "note": "host wall clock around nnmpc_chain_run incl. the PCIe transfers of the inputs and the records"}
+    ch.close(); qp.close()
+    return out
+
+
+def bench_nn(ctx, B, steps, warmup):
     """Config 5: structured-NN controller forward, CDU architecture [536, 832, 832, 832, 32]
     (RegulatorLayerWithoutUprev, cdu_train.py:33, :77-80), B states per GPU per step, f32 and bf16."""
     from industrial_nnmpc_2021_amd.nn import StructuredNN
     from oracle import nn as onn
+    lib = ctx.lib
     nx, nu, hid = 252, 32, 832
     dims = [2 * nx + nu, hid, hid, hid, nu]
     rng = np.random.default_rng(0)
@@ -69,333 +541,168 @@ def bench_nn(args, torch, dev, rank, world, dist):
         W.append(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i]))
         if i < 3:
             W.append(0.05 * rng.standard_normal(dims[i + 1]))
-    B = args.batch or (1 << 20)
     xscale = rng.uniform(0.5, 2.0, nx)
-    g = torch.Generator(device=dev); g.manual_seed(1000 + rank)
-    x = torch.randn((B, nx), dtype=torch.float64, device=dev, generator=g)
-    xs = 0.3 * torch.randn((B, nx), dtype=torch.float64, device=dev, generator=g)
-    us = torch.rand((B, nu), dtype=torch.float64, device=dev, generator=g) - 0.5
-    u = torch.empty((B, nu), dtype=torch.float64, device=dev)
+    g = np.random.default_rng(1000 + ctx.rank)
+    x_h = g.standard_normal((B, nx)); xs_h = 0.3 * g.standard_normal((B, nx)); us_h = g.uniform(-0.5, 0.5, (B, nu))
+    x_h[0] = xs_h[0]                                   # steady-state row: the structure gives u = clip(us) exactly
+    D = lib.DeviceArray
+    x, xs, us, u = D.from_host(x_h), D.from_host(xs_h), D.from_host(us_h), D((B, nu), np.float64)
     flops_per_state = 2 * 2 * sum(dims[i] * dims[i + 1] for i in range(4))   # both passes
     hidden_flops_per_state = 2 * 2 * sum(dims[i] * dims[i + 1] for i in range(3))   # the three hidden-layer GEMMs
     res = {}
+    k = min(B, 4096)
+    rows = np.concatenate(([0], np.sort(np.random.default_rng(9).choice(B, k - 1, replace=False)))) if B > k else np.arange(B)
+    ref = onn.control_input(W, x_h[rows], None, xs_h[rows], us_h[rows], xscale, -np.ones(nu), np.ones(nu), False)
     for mode in ("f32", "bf16"):
         net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu),
                            max_batch=262144, use_bf16=(mode == "bf16"))
         # 6 extra untimed forwards before the W warmup steps: on every box tried, ONE forward of the first ~100 ms of
         # sustained MFMA load starts ~40 ms late (device time of that call unchanged: the stream just starts later),
         # then none for the rest of the run; with K of a few steps that one stall would be a third of the timed region
-        for _ in range(6 + args.warmup):
+        for _ in range(6 + warmup):
             net.forward_device(B, x, None, xs, us, u)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter(); gm = 0.0; dm = 0.0; hm = 0.0; hl = 0
-        for _ in range(args.steps):
+        ctx.sync()
+        t0 = time.perf_counter(); gm = dm = hm = 0.0; hl = 0
+        for _ in range(steps):
             net.forward_device(B, x, None, xs, us, u)
             gm += net.last_ms()[0]; dm += net.last_ms()[1]
             hm += net.last_hidden_ms()[0]; hl += net.last_hidden_ms()[1]
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        k = 512
-        ref = onn.control_input(W, x[:k].cpu().numpy(), None, xs[:k].cpu().numpy(), us[:k].cpu().numpy(), xscale,
-                                -np.ones(nu), np.ones(nu), False)
-        err = float(np.abs(u[:k].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()))
-        res[mode] = dict(states_per_s=world * B * args.steps / dt, ms_per_step=1e3 * dt / args.steps,
-                         gemm_TFLOPs=flops_per_state * B * args.steps / (gm * 1e-3) / 1e12, max_rel_err_vs_fp64_oracle=err,
-                         device_ms_per_step=dm / args.steps, gemm_ms_per_step=gm / args.steps,
-                         hidden_TFLOPs=hidden_flops_per_state * B * args.steps / (hm * 1e-3) / 1e12,
+        ctx.sync()
+        dt = ctx.max_over_ranks(time.perf_counter() - t0)
+        u_h = u.to_host()
+        err = float(np.abs(u_h[rows] - ref).max() / max(1.0, np.abs(ref).max()))
+        res[mode] = dict(states_per_s=ctx.world * B * steps / dt, ms_per_step=1e3 * dt / steps,
+                         gemm_TFLOPs=flops_per_state * B * steps / (gm * 1e-3) / 1e12, max_rel_err_vs_fp64_oracle=err,
+                         rows_checked=int(rows.size), steady_state_row_exact=bool(np.array_equal(u_h[0], np.clip(us_h[0], -1, 1))),
+                         device_ms_per_step=dm / steps, gemm_ms_per_step=gm / steps,
+                         hidden_TFLOPs=hidden_flops_per_state * B * steps / (hm * 1e-3) / 1e12,
                          hidden_launches=hl, hidden_avg_launch_ms=hm / max(1, hl))
         net.close()
-    if rank == 0:
-        f, h = res["f32"], res["bf16"]
-        # HBM bytes per launch of the hidden-layer GEMMs from the PMC passes of profiles/r01i_pmc_nn.json (same batch,
-        # 262144 states per launch); algorithmic bytes = rows x (K + N) x element size, averaged over the 3 layers
-        pmc = os.path.join(ROOT, "profiles", "r01i_pmc_nn.json")
-        tr = {}
-        if os.path.exists(pmc) and B >= 262144:
-            for k, v in json.load(open(pmc))["kernels"].items():
-                tr[k.split("::")[-1].split("<")[0]] = v["hbm_bytes_per_launch"]
-        rows = 2 * min(B, 262144)
-        kavg = (((dims[0] + 63) // 64) * 64 + 2 * hid) / 3.0
-        out = {"metric": "structured-NN forward states/sec (CDU architecture)", "value": f["states_per_s"], "unit": "states/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": f["ms_per_step"],
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"cdu_neural_network: RegulatorLayerWithoutUprev {dims}, {B} states per GPU per step",
-                          "flops_per_state": flops_per_state},
-               "roofline": {"kernel": "gemm_nt_f32_k (128 x 128 tiles, v_mfma_f32_32x32x2_f32, bias + ReLU fused)", "bound": "mfma",
-                            "achieved": f["hidden_TFLOPs"], "peak": FP32_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": f["hidden_TFLOPs"] / FP32_PEAK_TFLOPS, "traffic": tr.get("gemm_nt_f32_k"),
-                            "launches": f["hidden_launches"], "avg_launch_ms": f["hidden_avg_launch_ms"],
-                            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_nn.json)",
-                            "algorithmic_bytes_per_launch": rows * (896 + 896) * 4,
-                            "algorithmic_flops": "2 passes x 2 x sum(d_in d_out) per state, unpadded (SURVEY 8d)"},
-               "parity": {"max_rel_err_vs_fp64_oracle": f["max_rel_err_vs_fp64_oracle"]},
-               "bf16": dict(h, roofline={"kernel": "gemm_nt_bf16_wide_k (256 x 208 tiles, v_mfma_f32_16x16x32_bf16, persistent workgroups)",
-                                         "bound": "mfma", "achieved": h["hidden_TFLOPs"], "peak": 2500.0, "unit": "TFLOP/s",
-                                         "frac": h["hidden_TFLOPs"] / 2500.0, "traffic": tr.get("gemm_nt_bf16_wide_k"),
-                                         "launches": h["hidden_launches"], "avg_launch_ms": h["hidden_avg_launch_ms"],
-                                         "algorithmic_flops": "2 passes x 2 x (d_in h + 2 h^2) per state over the three hidden-layer launches (gemm_TFLOPs: all four GEMMs incl. the HBM-bound head)",
-                                         "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_nn.json)",
-                                         "algorithmic_bytes_per_launch": rows * (kavg + hid) * 2})}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier(); dist.destroy_process_group()
+    for a in (x, xs, us, u):
+        a.free()
+    f, h = res["f32"], res["bf16"]
+    traffic, tnote = pmc_traffic(f"nn_b{B}")
+    rows2 = 2 * min(B, 262144)
+    kavg = (((dims[0] + 63) // 64) * 64 + 2 * hid) / 3.0
+    out = {"metric": "structured-NN forward states/sec (CDU architecture)", "value": f["states_per_s"], "unit": "states/s",
+           "ms_per_step": f["ms_per_step"], "dtype": "f32",
+           "config": {"workload": f"cdu_neural_network: RegulatorLayerWithoutUprev {dims}, {B} states per GPU per step",
+                      "flops_per_state": flops_per_state},
+           "roofline": {"kernel": "gemm_nt_f32_k (128 x 128 tiles, v_mfma_f32_32x32x2_f32, bias + ReLU fused)", "dtype": "f32", "bound": "mfma",
+                        "achieved": f["hidden_TFLOPs"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f["hidden_TFLOPs"] / FP32_PEAK_TFLOPS,
+                        "traffic": traffic.get("gemm_nt_f32_k"), "traffic_unit": "HBM bytes per launch; " + tnote,
+                        "launches": f["hidden_launches"], "avg_launch_ms": f["hidden_avg_launch_ms"],
+                        "algorithmic_bytes_per_launch": rows2 * (896 + 896) * 4,
+                        "algorithmic_flops": "2 passes x 2 x sum(d_in d_out) per state, unpadded (SURVEY 8d)"},
+           "parity": {"max_rel_err_vs_fp64_oracle": f["max_rel_err_vs_fp64_oracle"], "rows_checked": f["rows_checked"],
+                      "steady_state_row_exact": f["steady_state_row_exact"], "tolerance": 1e-4},
+           "f32": f,
+           "bf16": dict(h, tolerance=3e-2,
+                        roofline={"kernel": "gemm_nt_bf16_wide_k (256 x 208 tiles, v_mfma_f32_16x16x32_bf16, persistent workgroups)", "dtype": "bf16",
+                                  "bound": "mfma", "achieved": h["hidden_TFLOPs"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": h["hidden_TFLOPs"] / BF16_PEAK_TFLOPS, "traffic": traffic.get("gemm_nt_bf16_wide_k"),
+                                  "traffic_unit": "HBM bytes per launch; " + tnote,
+                                  "launches": h["hidden_launches"], "avg_launch_ms": h["hidden_avg_launch_ms"],
+                                  "algorithmic_flops": "2 passes x 2 x (d_in h + 2 h^2) per state over the three hidden-layer launches "
+                                                       "(gemm_TFLOPs: all four GEMMs incl. the HBM-bound head)",
+                                  "algorithmic_bytes_per_launch": rows2 * (kavg + hid) * 2})}
+    return out
 
 
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cdu", choices=["cdu", "cstrs", "nn"])
+    ap.add_argument("--workload", default="cdu", choices=["cdu", "cstrs", "nn", "chains"])
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step")
-    ap.add_argument("--slots", type=int, default=0, help="resident problems per wave")
+    ap.add_argument("--slots", type=int, default=0, help="resident problems per wave (PDIP path)")
     ap.add_argument("--sx", type=float, default=2.0, help="state spread of the synthetic samples")
+    ap.add_argument("--cpu-baseline", default="bounded", choices=["bounded", "full", "none"],
+                    help="full: also 1 thread and nproc processes on >= 4 CDU problems (minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--method", default="auto", choices=["auto", "pdip", "asm"],
                     help="auto: shared-inverse active-set pass + PDIP for what it leaves; pdip: PDIP path only")
     ap.add_argument("--no-pdip", action="store_true", help="skip the extra PDIP-path measurement")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive measurement (host buffers either side)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no configs / sweep / chains legs")
     ap.add_argument("--pdip-batch", type=int, default=0)
+    ap.add_argument("--parity-rows", type=int, default=32)
     args = ap.parse_args()
+    if args.no_cpu_baseline:
+        args.cpu_baseline = "none"
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    # NNMPC_FORCE_DIST=1: run the process-group code (RCCL init, gather, max-reduce) with a single rank too
-    use_dist = world > 1 or os.environ.get("NNMPC_FORCE_DIST") == "1"
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
+
+    ctx = Ctx(args)
+    rank, world = ctx.rank, ctx.world
+    common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "data": "synthetic"}
 
     if args.workload == "nn":
-        return bench_nn(args, torch, dev, rank, world, dist)
-    from industrial_nnmpc_2021_amd import synthetic
-    from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
-    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+        out = bench_nn(ctx, args.batch or (1 << 20), args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(dict(out, **common)))
+        return
+    if args.workload == "chains":
+        out = chains_leg(ctx, "cdu", args.batch or 149, max(args.steps, 8))
+        if rank == 0:
+            print(json.dumps(dict({"metric": "lock-step closed-loop chain steps/sec (CDU size)"}, **out, **common)))
+        return
 
-    B = args.batch or (100000 if args.workload == "cdu" else 131072)   # cdu: BASELINE.json configs[2], "100k sampled x0, 1 MI355X"
-    slots = args.slots or (1024 if args.workload == "cdu" else 8192)
-    pl = synthetic.plant(args.workload, seed=0)
-    P, tq, nu = build_regulator_matrices(pl)
-    n, n_aug, N = P.shape[0], tq.shape[1], pl["N"]
-    qp = BatchedBoxQP(P, tq, nu, max_batch=min(slots, B), method=args.method)
-
-    # every rank draws its own shard of the seeded sample stream
-    s = synthetic.samples(pl, B, seed=1000 + rank, sx=args.sx)
-    x0_h = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), axis=1)
-    lb_h, ub_h = pl["ulb"].T - s["us"], pl["uub"].T - s["us"]
-    x0 = torch.from_numpy(x0_h).to(dev)
-    lb = torch.from_numpy(np.ascontiguousarray(lb_h)).to(dev)
-    ub = torch.from_numpy(np.ascontiguousarray(ub_h)).to(dev)
-    us = torch.from_numpy(s["us"]).to(dev)
-    u = torch.empty((B, n), dtype=torch.float64, device=dev)
-    act = torch.empty((B, qp.words), dtype=torch.int32, device=dev)
-    status = torch.empty((B,), dtype=torch.int32, device=dev)
-    iters = torch.empty((B, 2), dtype=torch.int32, device=dev)
-    gathered = [torch.empty((B, nu), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
-
-    def step():
-        qp.solve_batch_device(B, x0, lb, ub, u, act, status, iters)
-        first = (u[:, :nu] + us).contiguous()      # get_control_sequence adds us back (:689); ut = useq[0:Nu] (:856)
-        if dist is not None:
-            dist.gather(first, gathered, dst=0)     # the single RCCL gather over xGMI
-        return first
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    qp.set_profiling(True)
-    qp.stats(reset=True)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    st = qp.stats()
-    status_h = status.cpu().numpy()
-    iters_h = iters.cpu().numpy()
-    qp.set_profiling(False)
-
-    def panel_roofline(stx):
-        fl, ms = stx["panel_flops"], stx["panel_ms"]
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM traffic per launch: bytes per algorithmic flop measured with rocprofv3 PMC passes
-        # (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied; profiles/r01_pmc_chol_panel.json)
-        # scaled to this run's flops per launch; null when that profile does not exist.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_chol_panel.json")
-        if args.workload == "cdu" and os.path.exists(pmc) and stx["panel_launches"]:
-            traffic = json.load(open(pmc))["hbm_bytes_per_algorithmic_flop"] * fl / stx["panel_launches"]
-        return {"kernel": "chol_panel_k", "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC-derived, see profiles/r01_pmc_chol_panel.json)",
-                "launches": stx["panel_launches"], "avg_launch_ms": ms / max(1, stx["panel_launches"]),
-                "time_share": {"chol_panel": ms / stx["total_ms"], "chol_diag": stx["diag_ms"] / stx["total_ms"],
-                               "trsv": stx["trsv_ms"] / stx["total_ms"]},
-                # whole-solve rate in the survey's dense-PDIP flop model: factorisations * n^3/3
-                "cholesky_flops_over_solve_time_TFLOPs": stx["factorizations"] * n ** 3 / 3 / (stx["total_ms"] * 1e-3) / 1e12}
-
-    if rank == 0:
-        out = {
-            "metric": "condensed-QP solves/sec (CDU offline datagen)" if args.workload == "cdu"
-                      else "condensed-QP solves/sec (CSTRs offline datagen)",
-            "value": world * B * args.steps / dt, "unit": "solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if st["asm_solved"] else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}_offline_data: synthetic {args.workload.upper()}-size plant "
-                                   f"(n={n} vars, m={2 * n} box rows, n_aug={n_aug}), {B} sampled x0 per GPU per step",
-                       "batch_per_gpu": B, "sx": args.sx, "method": args.method,
-                       "parallelism": f"dp{world} (sharded samples, 1 RCCL gather/step)"},
-            "solver": {"status_hist": np.bincount(status_h, minlength=3).tolist(),
-                       "solved_by_active_set_pass": int(st["asm_solved"]), "active_set_rounds_per_step": st["asm_rounds"] / args.steps,
-                       "solved_by_pdip_path": int(st["problems"] - st["asm_solved"]),
-                       "mean_pdip_iters": float(iters_h[:, 0].mean()), "mean_factorizations": float(iters_h[:, 1].mean())},
-        }
-        if st["asm_solved"]:
-            # shared-inverse active-set pass: two kernels carry the time; the one with the larger
-            # hipEvent share is reported as `roofline`, the other as `roofline_secondary`
-            # mean HBM bytes per launch of the kernels from the PMC passes of profiles/r01j_pmc_asm.json (scripts/pmc_hbm.py,
-            # same command, B = 100000); null at other batch sizes
-            pmc_asm, pmc_file = {}, os.path.join(ROOT, "profiles", "r01j_pmc_asm.json")
-            if args.workload == "cdu" and B == 100000 and os.path.exists(pmc_file):
-                for k, v in json.load(open(pmc_file))["kernels"].items():
-                    pmc_asm[k.split("::")[-1].split("<")[0]] = v["hbm_bytes_per_launch"]
-            gach = st["asm_gemm_flops"] / (st["asm_gemm_ms"] * 1e-3) / 1e12
-            gemm = {"kernel": "gemm_nt_f64_128_k (x_unc = x0 Kunc', XH = LAM Pinv inside the column window, one full-width pass; "
-                              "the f32 rounds' XH32 = LAM32 Pinv32 on gemm_nt_f32_kdyn_k is in the same time and flop count)",
-                    "bound": "mfma", "achieved": gach, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": gach / FP64_PEAK_TFLOPS,
-                    "traffic": pmc_asm.get("gemm_nt_f64_128_k"),
-                    "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01j_pmc_asm.json)",
-                    "launches": st["asm_gemm_launches"], "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]),
-                    "algorithmic_flops": "2 * (columns evaluated) * (own last active bound + 1) per running problem and round (columns = window past the round's last active bound) + x_unc = x0 Kunc' + one full-width pass per problem",
-                    "time_share": st["asm_gemm_ms"] / st["total_ms"]}
-            lach = st["asm_lambda_flops"] / (st["asm_lambda_ms"] * 1e-3) / 1e12
-            lam = {"kernel": "asm_lambda_reg32_k + asm_lambda_reg_k (|A|x|A| Cholesky + solves of the multiplier systems: one "
-                             "wave per problem, tiles in the MFMA accumulators; f32 rounds until the set settles, then fp64)",
-                   "bound": "mfma", "achieved": lach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": lach / FP64_PEAK_TFLOPS,
-                   # the gathered Pinv blocks (algorithmic_GBps below) come from L2 / Infinity Cache, not from HBM
-                   "traffic": pmc_asm.get("asm_lambda_reg32_k"),
-                   "traffic_fp64_kernel": pmc_asm.get("asm_lambda_reg_k"),
-                   "traffic_unit": "HBM bytes per launch of asm_lambda_reg32_k / asm_lambda_reg_k (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01j_pmc_asm.json)",
-                   "algorithmic_flops": "m^3/3 + 2 m^2 per problem and round, m = size of its active set (f32 and fp64 rounds "
-                                        "alike; priced against the fp64 MFMA peak)",
-                   "algorithmic_GBps": st["asm_lambda_bytes"] / (st["asm_lambda_ms"] * 1e-3) / 1e9,
-                   "launches": st["asm_rounds"], "avg_launch_ms": st["asm_lambda_ms"] / max(1, st["asm_rounds"]),
-                   "time_share": st["asm_lambda_ms"] / st["total_ms"],
-                   "note": "latency-bound, not throughput-bound: per problem a chain of |A| dependent pivot steps "
-                           "(16 x 16 diagonal tiles on the VALU) between the MFMA tile updates; 1024 problems in flight"}
-            first, second = (lam, gemm) if st["asm_lambda_ms"] >= st["asm_gemm_ms"] else (gemm, lam)
-            out["roofline"] = first
-            out["roofline_secondary"] = second
-            out["roofline"]["other_time_share"] = {"set_bookkeeping_kernels": st["asm_update_ms"] / st["total_ms"]}
-            out["solver"]["checked_with_P_itself"] = int(st["asm_full_checks"])
-            out["solver"]["inverse_check"] = {"max_abs_P_Pinv_minus_I": st["asm_e2max"], "max_abs_P_Kunc_plus_tq": st["asm_e1max"]}
-        else:
-            out["roofline"] = panel_roofline(st)
-        # ---- parity spot check against the fp64 oracle on the first problems of the batch
+    # cdu: BASELINE.json configs[2] "100k sampled x0, 1 MI355X"; at 8 GPUs configs[3] "1M sampled x0 over 8 GPUs" = 125 000 each
+    B = args.batch or ((125000 if world == 8 else 100000) if args.workload == "cdu" else 10000)
+    extras = world == 1 and not args.no_extras
+    res, h = bench_qp(ctx, args.workload, B, args.steps, args.warmup, args.sx, method=args.method, slots=args.slots,
+                      want_buffers=(rank == 0 and world == 1))
+    if rank != 0:
+        return
+    n, n_aug = (h["n"], h["tq"].shape[1]) if h else (None, None)
+    out = {"metric": "condensed-QP solves/sec (CDU offline datagen)" if args.workload == "cdu"
+                     else "condensed-QP solves/sec (CSTRs offline datagen)"}
+    out.update(res)
+    out.update(common)
+    wl = args.workload
+    out["config"] = {"workload": f"{wl}_offline_data: synthetic {wl.upper()}-size plant" + (f" (n={n} vars, m={2 * n} box rows, n_aug={n_aug})" if n else "")
+                                 + f", {B} sampled x0 per GPU per step, whole sequences u* written out",
+                     "batch_per_gpu": B, "total_batch": B * world, "sx": args.sx, "method": args.method,
+                     "parallelism": f"dp{world} (sharded samples, 1 RCCL gather of the first moves per step, nnmpc_comm_gather_rows)"}
+    if world == 1 and h is not None:
         if not args.no_parity:
-            from oracle import qp as oqp
-            k = 2 if args.workload == "cdu" else 8
-            u_h = u[:k].cpu().numpy()
-            a_h = act[:k].cpu().numpy().view(np.uint32)
-            errs, ham = [], 0
-            Ps = np.tril(P) + np.tril(P, -1).T
-            for b in range(k):
-                info = {"nu": nu}
-                xe = oqp.solve_exact_box(Ps, tq @ x0_h[b], np.tile(lb_h[b], N), np.tile(ub_h[b], N), info=info)
-                rows = np.zeros(2 * n, bool)
-                rows[info["active"]] = True
-                bits = np.unpackbits(a_h[b].view(np.uint8), bitorder="little")[:2 * n].astype(bool)
-                errs.append(float(np.abs(u_h[b] - xe).max() / max(1.0, np.abs(xe).max())))
-                ham += int((bits != rows).sum())
-            out["parity"] = {"checked": k, "max_rel_err_vs_fp64_oracle": max(errs), "active_set_hamming": ham}
-        # ---- the PDIP path (method="pdip") on the head of the same batch, with its own roofline
+            out["parity"] = parity_leg(h, args.parity_rows, 2000)
+        if extras:
+            out["first_move_output"] = first_move_leg(ctx, h, args.steps)
+            if wl == "cdu":
+                out["sweep_sx"] = sweep_leg(ctx, h, [1.0, 2.0, 3.0, 4.0], 2)
         if args.method == "auto" and not args.no_pdip:
-            Bp = min(B, args.pdip_batch or (2048 if args.workload == "cdu" else 16384))
-            qp2 = BatchedBoxQP(P, tq, nu, max_batch=min(slots, Bp), method="pdip")
-            u2 = torch.empty((Bp, n), dtype=torch.float64, device=dev)
-            act2 = torch.empty((Bp, qp.words), dtype=torch.int32, device=dev)
-            st2 = torch.empty((Bp,), dtype=torch.int32, device=dev)
-            it2 = torch.empty((Bp, 2), dtype=torch.int32, device=dev)
-            qp2.solve_batch_device(min(Bp, 256), x0, lb, ub, u2, act2, st2, it2)      # warm-up
-            qp2.set_profiling(True); qp2.stats(reset=True)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            qp2.solve_batch_device(Bp, x0, lb, ub, u2, act2, st2, it2)
-            torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
-            s2 = qp2.stats()
-            it2h = it2.cpu().numpy()
-            out["pdip_path"] = {"value": Bp / dt2, "unit": "solves/s", "batch": Bp, "dtype": "f32 (+f64 refinement)",
-                                "status_hist": np.bincount(st2.cpu().numpy(), minlength=3).tolist(),
-                                "mean_pdip_iters": float(it2h[:, 0].mean()), "mean_factorizations": float(it2h[:, 1].mean()),
-                                "max_abs_diff_vs_active_set_pass": float((u2 - u[:Bp]).abs().max()),
-                                "active_sets_equal": bool(torch.equal(act2, act[:Bp])),
-                                "roofline": panel_roofline(s2)}
-            qp2.close()
-        # ---- the same batch with host buffers either side (never `value`): pinned host tensors -> HBM over PCIe, the
-        # solve, first moves (what simulate_offline keeps, lib/linearMPC.py:856) or full sequences back to the host
-        if world == 1 and not args.no_host_io:
-            qp.set_profiling(False)
-            xh, lbh, ubh = (t.cpu().pin_memory() for t in (x0, lb, ub))
-            fh = torch.empty((B, nu), dtype=torch.float64).pin_memory()
-            uh = torch.empty((B, n), dtype=torch.float64).pin_memory()
-            hio = {}
-            for name, full in (("first_move", False), ("full_sequence", True)):
-                best = None
-                for _ in range(2):
-                    torch.cuda.synchronize(); t1 = time.perf_counter()
-                    x0.copy_(xh, non_blocking=True); lb.copy_(lbh, non_blocking=True); ub.copy_(ubh, non_blocking=True)
-                    torch.cuda.synchronize()
-                    qp.solve_batch_device(B, x0, lb, ub, u, act, status, iters)
-                    if full:
-                        uh.copy_(u, non_blocking=True)
-                    else:
-                        fh.copy_(u[:, :nu] + us, non_blocking=True)
-                    torch.cuda.synchronize(); d = time.perf_counter() - t1
-                    best = d if best is None else min(best, d)
-                hio[name + "_solves_per_s"] = B / best
-                hio[name + "_ms"] = 1e3 * best
-            hio["bytes_in"] = int(xh.numel() + lbh.numel() + ubh.numel()) * 8
-            hio["bytes_out_first_move"] = B * nu * 8
-            hio["bytes_out_full_sequence"] = B * n * 8
-            hio["note"] = "PCIe-inclusive: pinned host buffers -> HBM, solve, results -> pinned host buffers; best of 2"
-            out["host_io"] = hio
-            del uh, fh
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, x0_h, lb_h, ub_h,
-                                               budget_s=20.0 if args.workload == "cdu" else 10.0, workload=args.workload)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            out["pdip_path"] = pdip_leg(ctx, h, min(B, args.pdip_batch or (1024 if wl == "cdu" else 8192)))
+        if not args.no_host_io:
+            out["host_io"] = host_io_leg(ctx, h)
+        host = h["host"]
+        P, tq, nu, N = h["P"], h["tq"], h["nu"], h["N"]
+        h["qp"].close(); h["buf"].free()
+        if extras and wl == "cdu":
+            out["chains"] = chains_leg(ctx, "cdu", 149, 12, dict(pl=h["pl"], P=P, tq=tq, nu=nu))
+            cfg = {}
+            r2, h2 = bench_qp(ctx, "cstrs", 10000, max(args.steps, 5), 2, args.sx, want_buffers=True)
+            r2["config"] = {"workload": "cstrs_offline_data: synthetic CSTRs-size plant (n=540, m=1080, cond(P) = 4e7), 10000 sampled x0, 1 GPU"}
+            if not args.no_parity:
+                r2["parity"] = parity_leg(h2, 32, 2000)
+            if args.cpu_baseline != "none":
+                x2, l2, u2, _ = h2["host"]
+                r2["cpu_baseline"] = cpu_baseline(np.tril(h2["P"]) + np.tril(h2["P"], -1).T, h2["tq"], h2["nu"], h2["N"], x2[:1024], l2[:1024], u2[:1024],
+                                                  budget_s=4.0, workload="cstrs", full=False)
+            h2["qp"].close(); h2["buf"].free()
+            cfg["cstrs_10k"] = r2
+            cfg["nn_1m"] = bench_nn(ctx, 1 << 20, 5, 1)
+            out["configs"] = cfg
+        if args.cpu_baseline != "none":
+            out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, host[0][:64], host[1][:64], host[2][:64],
+                                               budget_s=20.0 if wl == "cdu" else 10.0, workload=wl, full=args.cpu_baseline == "full")
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

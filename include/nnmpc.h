@@ -105,6 +105,10 @@ typedef struct {
   double asm_e1max;          /* max |P Kunc + tq| of the verified inverse (nnmpc_qp_set_inverse) */
   double asm_e2max;          /* max |P Pinv - I| */
   int64_t asm_full_checks;   /* finished problems the inverse-error bound could not certify: checked with P itself */
+  double asm_lambda32_ms;    /* hipEvent time of the f32 instance of the main multiplier kernel (asm_lambda_reg32_k) alone */
+  double asm_lambda64_ms;    /* ... and of the fp64 instance (asm_lambda_reg_k) */
+  double asm_lambda32_flops; /* the part of asm_lambda_flops solved in f32 rounds (price it against the f32 MFMA peak) */
+  int64_t asm_lambda32_launches, asm_lambda64_launches;
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);
@@ -133,6 +137,19 @@ int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const do
                               const double* ub, const uint8_t* guess, double* u, uint32_t* active,
                               int32_t* status, int32_t* iters, int32_t ptr_kind);
 
+/* Same with a choice of what comes back in u:
+ *   NNMPC_OUT_SEQUENCE    u: B x n  -- the whole input sequence DenseQPRegulator.solve returns (lib/linearMPC.py:506-512)
+ *   NNMPC_OUT_FIRST_MOVE  u: B x nu -- useq[0:Nu], all that simulate_offline (:856) and control_law (:662-665) keep;
+ *                         every problem is still solved and certified over all n variables, only the write-out shrinks
+ *                         (3.6 GB -> 26 MB per 100 000 CDU-size problems).
+ * guess may be NULL (cold start).  Problems whose inputs hold a NaN / Inf or a bound pair with lb > ub are not solved:
+ * status NNMPC_ST_NUMERIC, u = NaN. */
+#define NNMPC_OUT_SEQUENCE 0
+#define NNMPC_OUT_FIRST_MOVE 1
+int nnmpc_qp_solve_batch_ex(nnmpc_qp* h, int32_t B, const double* x0, const double* lb,
+                            const double* ub, const uint8_t* guess, double* u, uint32_t* active,
+                            int32_t* status, int32_t* iters, int32_t ptr_kind, int32_t out_kind);
+
 /* Enables the shared-inverse active-set pass: Hinv = P^-1 (n x n, fp64), Kunc = -Hinv tq (n x n_aug).
  * All samples share P (reference lib/linearMPC.py:472), so on an active set A the equality-constrained
  * optimum is x = x_unc - Hinv[:,A] lam with lam = (Hinv_AA)^-1 (x_unc,A - b_A): a primal-dual active-set
@@ -142,6 +159,11 @@ int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const do
  * through the PDIP path. */
 int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc);
 
+/* out (B x nu) = u[:, 0:nu] + us for HBM-resident sequences u (B rows of ldu doubles): the absolute first moves, i.e.
+ * get_control_sequence's "+ tile(us)" (lib/linearMPC.py:689) restricted to what simulate_offline keeps (:856).
+ * us may be NULL.  Device pointers; returns after the kernel has finished. */
+int nnmpc_qp_first_moves(const double* u, int64_t ldu, const double* us, int32_t B, int32_t nu, double* out);
+int nnmpc_qp_dims(nnmpc_qp* h, int32_t* n, int32_t* nu, int32_t* n_aug);   /* sizes the handle was created with */
 int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on);
 int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset);
 
@@ -169,6 +191,84 @@ int nnmpc_nn_last_ms(nnmpc_nn* h, double* gemm_ms, double* total_ms);
  * dominant kernel from its own launches; the reference only has time.time() pairs around the whole call,
  * lib/controller_evaluation.py:849-860) */
 int nnmpc_nn_last_hidden_ms(nnmpc_nn* h, double* hidden_ms, int32_t* launches);
+
+/* ---- Lock-step closed-loop chains, device resident  <-  simulate_offline (lib/linearMPC.py:827-880), one OS process
+ * per chain in the reference (:814-825).  All nc chains of a task advance together; per step (loop :845-866):
+ *     x0 = [x - xs; uprev - us], bounds ulb - us / uub - us   (get_control_sequence :682-689)
+ *     regulator QP for all chains in ONE batched solve, warm-started on the previous step's active set shifted by one
+ *     stage; ut = useq[0:Nu] + us (:856, :689);  x+ = A x + B ut + Bd d (:860);  uprev+ = ut
+ * State (x, uprev), the target pairs (xs, us) and disturbances d of ALL T steps and the recorded trajectories stay in
+ * HBM; the host sees nothing until nnmpc_chain_run returns.  Records are [T][nc][.] like the arrays the reference
+ * saves per chain (:868-872) with the chain index in the middle. */
+typedef struct nnmpc_chain nnmpc_chain;
+/* A: nx x nx, B: nx x nu, Bd: nx x nd (row-major, host); ulb/uub: nu; x0: nx, uprev0: nu (every chain starts there,
+ * :808-813).  qp: the regulator handle (n_aug = nx + nu); it is borrowed, not owned. */
+int nnmpc_chain_create(nnmpc_chain** out, nnmpc_qp* qp, int32_t nc, int32_t nx, int32_t nu, int32_t nd,
+                       const double* A, const double* B, const double* Bd, const double* ulb,
+                       const double* uub, const double* x0, const double* uprev0);
+int nnmpc_chain_destroy(nnmpc_chain* c);
+/* xs: T x nc x nx, us: T x nc x nu, d: T x nc x nd  ->  x_rec: T x nc x nx, uprev_rec, u_rec: T x nc x nu (state and
+ * previous input BEFORE the move of step t, and that move), status: T x nc, all host or all device (ptr_kind).
+ * The chain state carries over between calls (T steps at a time); nnmpc_chain_reset puts every chain back to (x0, uprev0).
+ * warm_start = 0 solves every step cold (same results: every solve is certified). */
+int nnmpc_chain_run(nnmpc_chain* c, int32_t T, const double* xs, const double* us, const double* d,
+                    double* x_rec, double* uprev_rec, double* u_rec, int32_t* status,
+                    int32_t warm_start, int32_t ptr_kind);
+int nnmpc_chain_reset(nnmpc_chain* c);
+/* hipEvent time of the last nnmpc_chain_run and the part of it spent inside the regulator solves */
+int nnmpc_chain_last_ms(nnmpc_chain* c, double* total_ms, double* solve_ms);
+
+/* ---- Steady-state target problems, batched  <-  TargetSelector.solve -> cvxopt.solvers.qp(P, q, G, h, A, b)
+ * (lib/linearMPC.py:298-311), the other QP of every simulation step (:851).  With F = [I - A; H C] of full column rank
+ * the equalities [I - A, -B; HC, 0][xs; us] = b (:262-266) fix xs = Xb b + Xu us and leave nz = Nz equalities E us = Eb b
+ * on the inputs, so each (ysp, dhat) pair is the small QP
+ *     min 1/2 us' Pr us + (Qb b + Qy y + q0)' us   s.t.  E us = Eb b,  ulb <= us <= uub          (nu variables)
+ * with b = tb [ysp; dhat], y = ysp - Cd dhat; the shared matrices are formed once on the host (fp64).  One wave per
+ * problem: primal-dual active-set iterations on the KKT system of the free inputs and the equalities (<= nu + nz
+ * unknowns, Gaussian elimination with partial pivoting in LDS), fp64 throughout, KKT-certified. */
+typedef struct nnmpc_ts nnmpc_ts;
+/* Pr: nu x nu (symmetric positive definite), E: nz x nu, lb/ub: nu.  nu <= 64, nz <= 16. */
+int nnmpc_ts_create(nnmpc_ts** out, int32_t nu, int32_t nz, const double* Pr, const double* E,
+                    const double* lb, const double* ub);
+int nnmpc_ts_destroy(nnmpc_ts* h);
+/* q: B x nu, e: B x nz  ->  us: B x nu, lam_eq: B x nz (multipliers of the equalities, may be NULL), active: B x nu
+ * bytes (0 free / 1 at uub / 2 at ulb, may be NULL), status: B (NNMPC_ST_*) */
+int nnmpc_ts_solve_batch(nnmpc_ts* h, int32_t B, const double* q, const double* e, double* us,
+                         double* lam_eq, uint8_t* active, int32_t* status, int32_t ptr_kind);
+
+/* ---- Device plumbing: HBM buffers, copies and synchronisation for host programs that bind only this library. */
+int nnmpc_device_count(void);
+int nnmpc_set_device(int32_t dev);
+int nnmpc_device_synchronize(void);
+int nnmpc_dev_mem_info(uint64_t* free_bytes, uint64_t* total_bytes);
+int nnmpc_dev_malloc(void** out, uint64_t bytes);
+int nnmpc_dev_free(void* p);
+int nnmpc_dev_memset(void* p, int32_t value, uint64_t bytes);
+int nnmpc_memcpy_h2d(void* dst, const void* src, uint64_t bytes);
+int nnmpc_memcpy_d2h(void* dst, const void* src, uint64_t bytes);
+int nnmpc_memcpy_d2d(void* dst, const void* src, uint64_t bytes);
+int nnmpc_host_alloc_pinned(void** out, uint64_t bytes);
+int nnmpc_host_free_pinned(void* p);
+
+/* ---- One process per GPU, results gathered over xGMI (RCCL)  <-  the reference's parallel model: independent OS
+ * processes / cluster jobs on contiguous slices of the scenario signal (OfflineSimulator._split_scenarios,
+ * generate_data, lib/linearMPC.py:786-825) whose per-task files are concatenated afterwards (_post_process_data,
+ * lib/controller_evaluation.py:273-295).  Here every rank solves its contiguous shard with no communication and the
+ * first moves meet on one rank in ONE gather.  nnmpc_comm_unique_id is called by one rank, the 128 bytes reach the
+ * others by any side channel (bench.py: a file under /tmp, all ranks are on one node), then every rank calls
+ * nnmpc_comm_init with the HIP device it will use already current (nnmpc_set_device). */
+typedef struct nnmpc_comm nnmpc_comm;
+int nnmpc_comm_unique_id(void* id128);
+int nnmpc_comm_init(nnmpc_comm** out, const void* id128, int32_t rank, int32_t world);
+int nnmpc_comm_destroy(nnmpc_comm* c);
+int nnmpc_comm_rank(nnmpc_comm* c);
+int nnmpc_comm_world(nnmpc_comm* c);
+/* send: rows[rank] x row_doubles (device) -> recv on root: sum(rows) x row_doubles (device), rank blocks in rank
+ * order; rows: world entries (host), the same on every rank; ragged shards allowed.  Blocking. */
+int nnmpc_comm_gather_rows(nnmpc_comm* c, const double* send, const int64_t* rows, int32_t row_doubles,
+                           double* recv, int32_t root);
+int nnmpc_comm_allreduce_max(nnmpc_comm* c, double* value);   /* host scalar in/out */
+int nnmpc_comm_barrier(nnmpc_comm* c);                        /* device idle and every rank arrived */
 
 #ifdef __cplusplus
 }

@@ -1,11 +1,12 @@
 """Counterparts of the hot-path pieces of the reference's lib/controller_evaluation.py:
 the NN controller (forward on the GPU) and the PRBS sampler / training-data scaling
 that sit either side of the offline data-generation path."""
+import itertools
 import time
 
 import numpy as np
 
-from .linearMPC import LinearMPCController
+from .linearMPC import LinearMPCController, _save_training_data
 from .nn import StructuredNN
 
 
@@ -28,13 +29,48 @@ def sample_prbs_like(*, num_change, num_steps, lb, ub, mean_change, sigma_change
     return np.repeat(values, repeat, axis=0)
 
 
-def get_data_for_training(*, data, num_samples, scale=True):
-    """First num_samples rows + xscale = (max - min)/2 of x (reference _get_data_for_training :254-271)."""
-    out = {k: np.asarray(data[k])[:num_samples] for k in ("x", "uprev", "xs", "us", "u")}
-    xscale = 0.5 * (out["x"].max(axis=0) - out["x"].min(axis=0)) if scale else np.ones(out["x"].shape[1])
+def _get_data_for_training(*, data, num_samples, scale=True):
+    """First num_samples rows of the generated data; with ``scale`` also xscale = (max - min)/2 of x, x and xs divided
+    by it, returned as (data, xscale) -- without, the dict alone (reference :254-271, same return convention)."""
+    out = {k: np.asarray(data[k])[0:num_samples, :] for k in ("x", "uprev", "xs", "us", "u")}
+    if not scale:
+        return out
+    xscale = 0.5 * (np.max(out["x"], axis=0) - np.min(out["x"], axis=0))
     out["x"] = out["x"] / xscale
     out["xs"] = out["xs"] / xscale
-    return out, xscale
+    return (out, xscale)
+
+
+get_data_for_training = _get_data_for_training
+
+
+def _load_training_data(filename):
+    """One array per key (reference lib/python_utils.py:44-51); .h5 when h5py wrote it, else the .npz stand-in."""
+    try:
+        import h5py
+        with h5py.File(filename, "r") as f:
+            return {k: np.asarray(f.get(k)) for k in f.keys()}
+    except (ImportError, OSError):
+        with np.load(filename if filename.endswith(".npz") else filename + ".npz") as f:
+            return {k: f[k] for k in f.files}
+
+
+def _post_process_data(*, data_filename, num_data_gen_task, num_process_per_task):
+    """Concatenate the per-chain files '<task>-<proc>-<data_filename>' that generate_data wrote, task-major like the
+    reference (:273-295): rows of x / uprev / xs / us / u (and the solver's status) stacked, data_gen_time averaged;
+    the result is saved under data_filename and returned."""
+    training_data = {}
+    for (task, process) in itertools.product(range(num_data_gen_task), range(num_process_per_task)):
+        sub = _load_training_data(str(task) + '-' + str(process) + '-' + data_filename)
+        for key, value in sub.items():
+            training_data.setdefault(key, []).append(value)
+    for key in training_data:
+        if key == 'data_gen_time':
+            training_data[key] = np.mean(np.asarray(training_data[key]))
+        else:
+            training_data[key] = np.concatenate(training_data[key], axis=0)
+    _save_training_data(training_data, data_filename)
+    return training_data
 
 
 def relu(x):

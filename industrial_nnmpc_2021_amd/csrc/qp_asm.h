@@ -31,7 +31,8 @@ namespace nnmpc {
 
 constexpr int ASM_MLDS = 176;      // largest active set factored in LDS (11 x 11 lower 16x16 fp64 tiles)
 constexpr int ASM_TS = 16 * 17;    // doubles per LDS tile (16 rows, stride 17: conflict-free MFMA operand reads)
-enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4 };   // CERT: finished and certified by the inverse-error bound
+enum { ASM_RUN = 0, ASM_DONE = 1, ASM_FALLBACK = 2, ASM_CERT = 3, ASM_WIDE = 4, ASM_INVALID = 5 };   // CERT: finished and certified by the
+                                   // inverse-error bound; INVALID: NaN / Inf in x0 or lb > ub (status NNMPC_ST_NUMERIC, u = NaN)
 constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: class b holds sets of 16 (b + 4) or fewer
 constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds): four problems per workgroup (asm_lambda_reg_k); 6, 7: two
 constexpr int ASM_NCNT = 40;       // ints in AsmDev::counters
@@ -109,10 +110,11 @@ struct AsmDev {
   const double* xhw;               // [rows] = lamw * H, all columns
   int* wlist;                      // [ASM_NKG][wcap] those problems by k-group; their numbers are counters[ASM_CNT_WIDEG + g]
   int wcap;                        // rows per region of lamw / xhw / wlist
-  double* work;                    // [nseg][2] statistics: fp64 flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels
+  double* work;                    // [nseg][3] statistics: flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels, flops of the f32 rounds
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
-  double* u_out;
+  double* u_out;                   // [nseg][ldu]: the first nout entries of every solution (nout = n: whole sequences,
+  int ldu, nout;                   // nout = nu: first moves only -- all the offline simulation keeps, lib/linearMPC.py:856)
   uint32_t* act_out;
   int* status_out;
   int* iters_out;
@@ -143,9 +145,15 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     }
     d.st[(size_t)p * d.n + r] = (unsigned char)s;
   }
+  // inputs the tests below cannot reason about (every comparison with a NaN is false, so a NaN would pass for
+  // "feasible"): NaN / Inf in x0, a NaN bound, lb > ub.  Such a problem is not solved at all.
+  int invalid = 0;
+  for (int k = tid; k < d.nu; k += 256) invalid |= !(d.lb[(size_t)p * d.nu + k] <= d.ub[(size_t)p * d.nu + k]);
+  for (int k = tid; k < d.ka; k += 256) invalid |= !(fabs(d.x0[(size_t)p * d.ka + k]) <= 1.79e308);
+  invalid = __syncthreads_or(invalid);
   // an empty set runs one round like the others: x = x_unc is checked and certified by asm_update_k / asm_wide_k
   if (tid == 0) {
-    d.rounds[p] = 0; d.state[p] = ASM_RUN;
+    d.rounds[p] = 0; d.state[p] = invalid ? ASM_INVALID : ASM_RUN;
     d.prec[p] = (d.use_f32 && !d.guess) ? 0 : 1;       // a caller's guess is expected to be right: confirm it in fp64 at once
     d.redo[p] = 0;
     d.ninf_best[p] = 0x7fffffff; d.alpha[p] = ASM_GRACE;
@@ -207,8 +215,9 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
     d.mg[p] = m;
     if (m <= d.max_active && d.work) {
       const double md = (double)m;
-      d.work[2 * p] += md * md * md / 3.0 + 2.0 * md * md;             // per-problem slots: same-address atomics
-      d.work[2 * p + 1] += 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md);   // (one per workgroup) serialise the launch
+      d.work[3 * p] += md * md * md / 3.0 + 2.0 * md * md;             // per-problem slots: same-address atomics
+      d.work[3 * p + 1] += 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md);   // (one per workgroup) serialise the launch
+      if (d.prec[p] == 0 && m <= ASM_MLDS) d.work[3 * p + 2] += md * md * md / 3.0 + 2.0 * md * md;   // ... of which in an f32 round
     }
     if (m > d.max_active) d.state[p] = ASM_FALLBACK;
   }
@@ -989,7 +998,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
       const int k = r % d.nu, s = st[r];
       const double x = s == 0 ? d.xunc[o + r] - d.xh[orow + r]
                               : (s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
-      d.u_out[(size_t)p * d.n + r] = x;
+      if (r < d.nout) d.u_out[(size_t)p * d.ldu + r] = x;
       if (!sure) d.x[o + r] = x;                             // as a GEMM row too if P itself must confirm it
     }
   }
@@ -1039,7 +1048,7 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
       l1 += fabs(l); lmin = fmin(lmin, fabs(l));
       x = s == 1 ? ub : lb;
     }
-    d.u_out[(size_t)p * d.n + r] = x;                        // final if nothing changes
+    if (r < d.nout) d.u_out[(size_t)p * d.ldu + r] = x;      // final if nothing changes
   }
   double x1 = 0.0;
   for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
@@ -1060,7 +1069,11 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
   const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
   const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
   if (tot == 0 && !sure) {                                   // P itself has to confirm this one: x as a GEMM row
-    for (int r = tid; r < d.n; r += 256) d.x[o + r] = d.u_out[(size_t)p * d.n + r];
+    for (int r = tid; r < d.n; r += 256) {                   // (nothing changed: st still is the set x belongs to)
+      const int k = r % d.nu, s = st[r];
+      d.x[o + r] = s == 0 ? d.xunc[o + r] - (r < Wp ? d.xh[onar + r] : d.xhw[orow + r])
+                          : (s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+    }
   }
   if (tid == 0) {
     if (tot == 0) {
@@ -1221,7 +1234,8 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
         x = d.xunc[o + r] - ((a0 + a1) + (a2 + a3));
         if (x > ub + d.bound_tol) dc = 1; else if (x < lb - d.bound_tol) dc = 2;
       } else x = sr == 1 ? ub : lb;
-      d.u_out[(size_t)p * d.n + r] = x;                      // final once nothing changes
+      if (r < d.nout) d.u_out[(size_t)p * d.ldu + r] = x;    // final once nothing changes
+      d.x[o + r] = x;                                        // ... and as a GEMM row, should P itself have to confirm it
       dec[r] = dc;
       if (dc != 255) { ++ninf; rmin = min(rmin, r); }
     }
@@ -1258,7 +1272,6 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       const double QI = d.tqmax * X1;
       const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
       const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
-      if (!sure) for (int r = tid; r < d.n; r += 256) d.x[o + r] = d.u_out[(size_t)p * d.n + r];   // P itself has to confirm it
       if (tid == 0) {
         d.state[p] = sure ? ASM_CERT : ASM_DONE;
         if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);
@@ -1374,6 +1387,16 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
   __shared__ double gq[4];
   const int p = blockIdx.x, tid = threadIdx.x;
   const int stt = d.state[p];
+  if (stt == ASM_INVALID) {                     // rejected by asm_init_k: no solution, no active set
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int r = tid; r < d.nout; r += 256) d.u_out[(size_t)p * d.ldu + r] = qnan;
+    if (d.act_out) for (int w = tid; w < d.words; w += 256) d.act_out[(size_t)p * d.words + w] = 0u;
+    if (tid == 0) {
+      if (d.status_out) d.status_out[p] = 2;    // NNMPC_ST_NUMERIC
+      if (d.iters_out) { d.iters_out[2 * p] = 0; d.iters_out[2 * p + 1] = 0; }
+    }
+    return;
+  }
   if (stt != ASM_DONE && stt != ASM_CERT) {
     if (tid == 0 && d.status_out) d.status_out[p] = 3;   // marks "not solved here" for the caller
     return;
@@ -1390,9 +1413,10 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
       const int s = st[r];
       const double g = d.px[o + r] + d.q64[o + r];
       qm = fmax(qm, fabs(d.q64[o + r]));
-      if (s == 0) { gf = fmax(gf, fabs(g)); bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); }
-      else if (s == 1) bad += g >= 0.0;
-      else bad += g <= 0.0;
+      // every test is written so that a NaN fails it (fmax / a plain "violated?" comparison would let it through)
+      if (s == 0) { bad += !(fabs(g) <= 1.79e308); gf = fmax(gf, fabs(g)); bad += !(x <= ub + d.bound_tol) || !(x >= lb - d.bound_tol); }
+      else if (s == 1) bad += !(g < 0.0);
+      else bad += !(g > 0.0);
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -1408,7 +1432,7 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
   if ((tid & 63) == 0) gq[tid >> 6] = gf;
   __syncthreads();
   const double gfm = fmax(fmax(gq[0], gq[1]), fmax(gq[2], gq[3]));
-  const int ok = nbad == 0 && gfm <= d.stat_tol * fmax(gscale_min, qs);
+  const int ok = nbad == 0 && gfm <= d.stat_tol * fmax(gscale_min, qs);   // (a NaN in q makes qs NaN -> fmax -> gscale_min: still a finite bar)
   if (d.act_out) {
     // bit k*2nu + c: upper bound of variable k*nu + c active, bit k*2nu + nu + c: lower bound (row order of the
     // reference's G).  One pass over the bound states (one division per variable), words assembled in LDS.
@@ -1459,11 +1483,11 @@ __global__ void asm_gather_guess_k(unsigned char* guess, const unsigned char* st
 }
 __global__ void asm_scatter_k(double* u, uint32_t* act, int* status, int* iters, const double* uc,
                               const uint32_t* actc, const int* stc, const int* itc, const int* list, int cnt,
-                              int n, int words) {
+                              int n, int words, int ldu, int nout) {
   const int i = blockIdx.x;
   if (i >= cnt) return;
   const int p = list[i];
-  for (int k = threadIdx.x; k < n; k += blockDim.x) u[(size_t)p * n + k] = uc[(size_t)i * n + k];
+  for (int k = threadIdx.x; k < nout; k += blockDim.x) u[(size_t)p * ldu + k] = uc[(size_t)i * n + k];
   if (act) for (int k = threadIdx.x; k < words; k += blockDim.x) act[(size_t)p * words + k] = actc[(size_t)i * words + k];
   if (threadIdx.x == 0) {
     if (status) status[p] = stc[i];

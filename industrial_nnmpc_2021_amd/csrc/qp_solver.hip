@@ -62,7 +62,8 @@ struct QpDev {
   float *mu, *gap, *smu, *qscale;
   double* rz;
   int* counters;
-  double* u_out;       // [slots][n]
+  double* u_out;       // [problems][ldu]: the first nout entries of every solution
+  int ldu, nout;
   uint32_t* act_out;   // [slots][words]
   int* status_out;     // [slots]
   int* iters_out;      // [slots][2]
@@ -120,6 +121,8 @@ __device__ int block_sum_i(int v, int* sh) {
 
 #define SLACK_MIN 1e-12f
 
+__device__ void write_outputs(const QpDev& d, int p, int status);
+
 // ---------------------------------------------------------------------------
 // Continuous batching: every free (DONE) slot grabs the next unsolved problem of
 // the segment and is initialised for the PDIP (warm start = clipped u_unc).
@@ -142,9 +145,11 @@ __global__ __launch_bounds__(256) void refill_k(QpDev d) {
     d.ub64[(size_t)p * d.nu + tid] = d.ub_all[(size_t)idx * d.nu + tid];
   }
   float qm = 0.f;
+  int invalid = 0;
   for (int r = tid; r < d.np; r += 256) {
     if (r < d.n) {
       const int c = r % d.nu;
+      invalid |= !(fabs(d.q64_all[oi + r]) <= 1.79e308);   // (fmaxf below would drop a NaN)
       const float lb = (float)d.lb_all[(size_t)idx * d.nu + c], ub = (float)d.ub_all[(size_t)idx * d.nu + c];
       const double q64 = d.q64_all[oi + r];
       const float q = (float)(q64 / d.pscale);
@@ -162,6 +167,20 @@ __global__ __launch_bounds__(256) void refill_k(QpDev d) {
     d.r64[o + r] = 0.0; d.p64[o + r] = 0.0; d.v64[o + r] = 0.0;
   }
   qm = block_max(qm, shf);
+  {
+    // NaN / Inf in q (i.e. in x0) or a bound pair with lb > ub (or a NaN): not solved at all -- status NUMERIC, u = NaN
+    invalid |= !(qm <= 3.0e38f);
+    if (tid < d.nu) invalid |= !(d.lb_all[(size_t)idx * d.nu + tid] <= d.ub_all[(size_t)idx * d.nu + tid]);
+    invalid = __syncthreads_or(invalid);
+    if (invalid) {
+      const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+      for (int r = tid; r < d.np; r += 256) d.x[o + r] = qnan;
+      if (tid == 0) { d.slot_prob[p] = idx; d.fail[p] = 1; d.ipm_it[p] = d.nfac[p] = 0; }
+      __syncthreads();
+      write_outputs(d, p, NNMPC_ST_NUMERIC);       // the slot stays free (PH_DONE) and takes the next problem next round
+      return;
+    }
+  }
   // (a guess row that starts with 255 means: no guess for this problem)
   const bool warm = d.guess_all != nullptr && d.guess_all[(size_t)idx * d.n] != 255;
   if (warm) {
@@ -203,7 +222,7 @@ __device__ void write_outputs(const QpDev& d, int p, int status) {
   const int tid = threadIdx.x;
   const size_t o = (size_t)p * d.np;
   const size_t pi = (size_t)d.slot_prob[p];
-  for (int r = tid; r < d.n; r += 256) d.u_out[pi * d.n + r] = d.x[o + r];
+  for (int r = tid; r < d.nout; r += 256) d.u_out[pi * d.ldu + r] = d.x[o + r];
   const int m = 2 * d.n;
   for (int w = tid; w < d.words; w += 256) {
     uint32_t bits = 0;
@@ -306,9 +325,10 @@ __device__ int kkt_check(const QpDev& d, int p, int* shi, double* shd) {
     const double g = d.PX[o + r] + d.q64[o + r], x = d.x[o + r];
     const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
     const int s = d.st[o + r];
-    if (s == 0) { bad += (x > ub + d.bound_tol) || (x < lb - d.bound_tol); gfree = fmax(gfree, fabs(g)); }
-    else if (s == 1) bad += (g >= 0.0);   // multiplier -g must be > 0
-    else bad += (g <= 0.0);               // multiplier  g must be > 0
+    // (written so that a NaN fails every test)
+    if (s == 0) { bad += !(x <= ub + d.bound_tol) || !(x >= lb - d.bound_tol) || !(fabs(g) <= 1.79e308); gfree = fmax(gfree, fabs(g)); }
+    else if (s == 1) bad += !(g < 0.0);   // multiplier -g must be > 0
+    else bad += !(g > 0.0);               // multiplier  g must be > 0
   }
   bad = block_sum_i(bad, shi);
   gfree = block_maxd(gfree, shd);
@@ -670,6 +690,11 @@ struct nnmpc_qp {
   std::vector<EvRec> ev_recs;
   nnmpc_qp_stats stats;
   std::vector<void*> allocs;
+  // grow-only scratch owned by the handle: staging of host-pointer calls, compacted copies for the PDIP fallback
+  struct Scratch { void* p = nullptr; size_t cap = 0; };
+  enum { SC_U = 0, SC_ACT, SC_ST, SC_IT, SC_GUESS, SC_FB_GUESS, SC_FB_LIST, SC_FB_X0, SC_FB_LB, SC_FB_UB, SC_FB_U, SC_FB_ACT, SC_FB_ST, SC_FB_IT, SC_COUNT };
+  Scratch sc[SC_COUNT];
+  int ldu, nout;        // layout of the caller's u buffer for the call in progress (nnmpc_qp_solve_batch_ex)
 };
 
 namespace {
@@ -683,6 +708,21 @@ int dev_alloc(nnmpc_qp* h, T** p, size_t count) {
   if (e != hipSuccess) { set_error("hipMemset: %s", hipGetErrorString(e)); return NNMPC_EHIP; }
   h->allocs.push_back(q);
   *p = (T*)q;
+  return 0;
+}
+
+// scratch buffer `which` of at least `bytes` (contents undefined); grown buffers replace the old ones
+template <class T>
+int scratch_get(nnmpc_qp* h, int which, T** out, size_t bytes) {
+  nnmpc_qp::Scratch& s = h->sc[which];
+  if (s.cap < bytes) {
+    if (s.p) { hipFree(s.p); s.p = nullptr; s.cap = 0; }
+    const size_t want = bytes + bytes / 4 + 256;
+    const hipError_t e = hipMalloc(&s.p, want);
+    if (e != hipSuccess) { s.p = nullptr; set_error("hipMalloc(%zu bytes of scratch): %s", want, hipGetErrorString(e)); return NNMPC_ENOMEM; }
+    s.cap = want;
+  }
+  *out = (T*)s.p;
   return 0;
 }
 
@@ -718,6 +758,8 @@ void ev_collect(nnmpc_qp* h) {
     else if (r.kind == 4) h->stats.asm_lambda_ms += ms;
     else if (r.kind == 5) { h->stats.asm_gemm_ms += ms; h->stats.asm_gemm_flops += r.flops; h->stats.asm_gemm_launches += 1; }
     else if (r.kind == 6) h->stats.asm_update_ms += ms;
+    else if (r.kind == 7) { h->stats.asm_lambda32_ms += ms; h->stats.asm_lambda32_launches += 1; }
+    else if (r.kind == 8) { h->stats.asm_lambda64_ms += ms; h->stats.asm_lambda64_launches += 1; }
   }
   h->ev_recs.clear();
   h->ev_used = 0;
@@ -818,6 +860,7 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
   d.seg_count = nprob;
   d.guess_all = guess_dev;
   d.u_out = u_dev; d.act_out = act_dev; d.status_out = st_dev; d.iters_out = it_dev;
+  d.ldu = h->ldu; d.nout = h->nout;
   hipLaunchKernelGGL(reset_slots_k, dim3((rows + 255) / 256), dim3(256), 0, s, d);
 
   int cnt[8];
@@ -885,7 +928,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
   a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
-  a.u_out = u_dev; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
+  a.u_out = u_dev; a.ldu = h->ldu; a.nout = h->nout; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
   // asm_update_k / asm_wide_k of the same round
@@ -970,8 +1013,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       }
       // fp64 first (its waves are the long ones), then the f32 rounds of the problems whose set still moves
-      if (nreg_wg) hipLaunchKernelGGL(asm_lambda_reg_k, dim3(nreg_wg), dim3(256), ASM_REG_LDS, s, a);
-      if (nreg32_wg) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3(nreg32_wg), dim3(256), ASM_REG32_LDS, s, a);
+      if (nreg_wg) { EvScope e8(h, 8, 0.0); hipLaunchKernelGGL(asm_lambda_reg_k, dim3(nreg_wg), dim3(256), ASM_REG_LDS, s, a); }
+      if (nreg32_wg) { EvScope e7(h, 7, 0.0); hipLaunchKernelGGL(asm_lambda_reg32_k, dim3(nreg32_wg), dim3(256), ASM_REG32_LDS, s, a); }
       if (nbig) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     {
@@ -1013,47 +1056,51 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   HIPCHK(stream_sync(s));
   HIPCHK(hipGetLastError());
   std::vector<int> fb;
-  for (int p = 0; p < nprob; ++p) if (st[p] != 0) fb.push_back(p);
-  h->stats.asm_solved += nprob - (int64_t)fb.size();
+  int ninvalid = 0;
+  for (int p = 0; p < nprob; ++p) { if (st[p] == 3) fb.push_back(p); else if (st[p] != 0) ++ninvalid; }   // 2: rejected inputs
+  h->stats.asm_solved += nprob - (int64_t)fb.size() - ninvalid;
   if (st_dev) HIPCHK(hipMemcpyAsync(st_dev, h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (fb.empty()) { h->stats.problems += nprob; return 0; }
   if (h->opts.method == 2) {                           // asm only: report the rest as not certified
-    for (int& v : st) v = v ? NNMPC_ST_MAXITER : 0;
+    for (int& v : st) v = v == 3 ? NNMPC_ST_MAXITER : v;
     if (st_dev) HIPCHK(hipMemcpy(st_dev, st.data(), (size_t)nprob * sizeof(int), hipMemcpyHostToDevice));
     h->stats.problems += nprob;
     return 0;
   }
-  // ---- PDIP fallback on the compacted remainder
+  // ---- PDIP fallback on the compacted remainder (scratch owned by the handle: nothing to release on an error path)
   const int cntf = (int)fb.size();
   int* list = nullptr; double *x0c = nullptr, *lbc = nullptr, *ubc = nullptr, *uc = nullptr;
   uint32_t* actc = nullptr; int *stc = nullptr, *itc = nullptr;
   unsigned char* guessc = nullptr;
-  HIPCHK(hipMalloc((void**)&guessc, (size_t)cntf * h->n));
-  HIPCHK(hipMalloc((void**)&list, cntf * sizeof(int)));
-  HIPCHK(hipMalloc((void**)&x0c, (size_t)cntf * h->n_aug * 8));
-  HIPCHK(hipMalloc((void**)&lbc, (size_t)cntf * h->nu * 8));
-  HIPCHK(hipMalloc((void**)&ubc, (size_t)cntf * h->nu * 8));
-  HIPCHK(hipMalloc((void**)&uc, (size_t)cntf * h->n * 8));
-  HIPCHK(hipMalloc((void**)&actc, (size_t)cntf * h->words * 4));
-  HIPCHK(hipMalloc((void**)&stc, (size_t)cntf * 4));
-  HIPCHK(hipMalloc((void**)&itc, (size_t)cntf * 8));
+  int rc = 0;
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_GUESS, &guessc, (size_t)cntf * h->n);
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_LIST, &list, cntf * sizeof(int));
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_X0, &x0c, (size_t)cntf * h->n_aug * 8);
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_LB, &lbc, (size_t)cntf * h->nu * 8);
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_UB, &ubc, (size_t)cntf * h->nu * 8);
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_U, &uc, (size_t)cntf * h->n * 8);
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_ACT, &actc, (size_t)cntf * h->words * 4);
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_ST, &stc, (size_t)cntf * 4);
+  if (!rc) rc = scratch_get(h, nnmpc_qp::SC_FB_IT, &itc, (size_t)cntf * 8);
+  if (rc) return rc;
   HIPCHK(hipMemcpy(list, fb.data(), cntf * sizeof(int), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(asm_gather_k, dim3(cntf), dim3(128), 0, s, x0c, lbc, ubc, x0_dev, lb_dev, ub_dev, list, cntf, h->n_aug, h->nu);
   // a problem whose set had settled but failed the check with P (inverse too inaccurate for its x) starts the polish
   // on that set; the others (not settled, too large, not positive definite) run the PDIP from scratch
   hipLaunchKernelGGL(asm_gather_guess_k, dim3(cntf), dim3(128), 0, s, guessc, h->asm_st, h->asm_state, list, cntf, h->n);
-  int rc = 0;
+  const int ldu_caller = h->ldu, nout_caller = h->nout;
+  h->ldu = h->n; h->nout = h->n;                       // the compacted copies hold whole sequences
   for (int b0 = 0; b0 < cntf && !rc; b0 += h->seg_max) {
     const int nb = std::min(h->seg_max, cntf - b0);
     rc = solve_segment(h, nb, x0c + (size_t)b0 * h->n_aug, lbc + (size_t)b0 * h->nu, ubc + (size_t)b0 * h->nu, guessc + (size_t)b0 * h->n,
                        uc + (size_t)b0 * h->n, actc + (size_t)b0 * h->words, stc + b0, itc + 2 * (size_t)b0);
   }
+  h->ldu = ldu_caller; h->nout = nout_caller;
   if (!rc) {
     hipLaunchKernelGGL(asm_scatter_k, dim3(cntf), dim3(128), 0, s, u_dev, act_dev, st_dev, it_dev, uc, actc, stc, itc,
-                       list, cntf, h->n, h->words);
+                       list, cntf, h->n, h->words, h->ldu, h->nout);
     HIPCHK(stream_sync(s));
   }
-  hipFree(guessc); hipFree(list); hipFree(x0c); hipFree(lbc); hipFree(ubc); hipFree(uc); hipFree(actc); hipFree(stc); hipFree(itc);
   h->stats.problems += nprob - cntf;   // solve_segment counted the fallback ones
   return rc;
 }
@@ -1077,6 +1124,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   memset(&h->stats, 0, sizeof(h->stats));
   memset(&h->d, 0, sizeof(h->d));
   h->profiling = false; h->ev_used = 0; h->have_inverse = false;
+  h->ldu = n; h->nout = n;
   if (opts) h->opts = *opts; else memset(&h->opts, 0, sizeof(h->opts));
   nnmpc_qp_opts& o = h->opts;
   if (o.max_batch <= 0) o.max_batch = 1024;
@@ -1168,7 +1216,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NLIST * G);
-  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 2 * G);
+  A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 3 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_
   if (rc) { nnmpc_qp_destroy(h); return rc; }
@@ -1236,6 +1284,7 @@ int nnmpc_qp_destroy(nnmpc_qp* h) {
   if (!h) return NNMPC_OK;
   hipDeviceSynchronize();
   for (void* p : h->allocs) hipFree(p);
+  for (auto& sc : h->sc) if (sc.p) hipFree(sc.p);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -1298,6 +1347,14 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
   return NNMPC_OK;
 }
 
+int nnmpc_qp_dims(nnmpc_qp* h, int32_t* n, int32_t* nu, int32_t* n_aug) {
+  if (!h) { set_error("nnmpc_qp_dims: null handle"); return NNMPC_EINVAL; }
+  if (n) *n = h->n;
+  if (nu) *nu = h->nu;
+  if (n_aug) *n_aug = h->n_aug;
+  return NNMPC_OK;
+}
+
 int nnmpc_qp_set_profiling(nnmpc_qp* h, int32_t on) {
   if (!h) return NNMPC_EINVAL;
   h->profiling = on != 0;
@@ -1309,11 +1366,11 @@ int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
   *out = h->stats;
   out->asm_e1max = h->asm_e1max; out->asm_e2max = h->asm_e2max;
   {
-    std::vector<double> w(2 * (size_t)h->seg_max, 0.0);
+    std::vector<double> w(3 * (size_t)h->seg_max, 0.0);
     hipMemcpy(w.data(), h->asm_work, w.size() * sizeof(double), hipMemcpyDeviceToHost);
-    double f = 0.0, b = 0.0;
-    for (size_t i = 0; i < w.size(); i += 2) { f += w[i]; b += w[i + 1]; }
-    out->asm_lambda_flops = f; out->asm_lambda_bytes = b;
+    double f = 0.0, b = 0.0, f32 = 0.0;
+    for (size_t i = 0; i < w.size(); i += 3) { f += w[i]; b += w[i + 1]; f32 += w[i + 2]; }
+    out->asm_lambda_flops = f; out->asm_lambda_bytes = b; out->asm_lambda32_flops = f32;
     if (reset) hipMemset(h->asm_work, 0, w.size() * sizeof(double));
   }
   {
@@ -1328,64 +1385,72 @@ int nnmpc_qp_get_stats(nnmpc_qp* h, nnmpc_qp_stats* out, int32_t reset) {
 
 int nnmpc_qp_solve_batch(nnmpc_qp* h, int32_t B, const double* x0, const double* lb, const double* ub,
                          double* u, uint32_t* active, int32_t* status, int32_t* iters, int32_t ptr_kind) {
-  return nnmpc_qp_solve_batch_warm(h, B, x0, lb, ub, nullptr, u, active, status, iters, ptr_kind);
+  return nnmpc_qp_solve_batch_ex(h, B, x0, lb, ub, nullptr, u, active, status, iters, ptr_kind, NNMPC_OUT_SEQUENCE);
 }
 
 int nnmpc_qp_solve_batch_warm(nnmpc_qp* h, int32_t B, const double* x0, const double* lb, const double* ub,
                               const uint8_t* guess, double* u, uint32_t* active, int32_t* status,
                               int32_t* iters, int32_t ptr_kind) {
+  return nnmpc_qp_solve_batch_ex(h, B, x0, lb, ub, guess, u, active, status, iters, ptr_kind, NNMPC_OUT_SEQUENCE);
+}
+
+int nnmpc_qp_solve_batch_ex(nnmpc_qp* h, int32_t B, const double* x0, const double* lb, const double* ub,
+                            const uint8_t* guess, double* u, uint32_t* active, int32_t* status,
+                            int32_t* iters, int32_t ptr_kind, int32_t out_kind) {
   if (!h || B < 0 || !x0 || !lb || !ub || !u) { set_error("nnmpc_qp_solve_batch: bad arguments"); return NNMPC_EINVAL; }
+  if (out_kind != NNMPC_OUT_SEQUENCE && out_kind != NNMPC_OUT_FIRST_MOVE) { set_error("nnmpc_qp_solve_batch_ex: bad out_kind %d", out_kind); return NNMPC_EINVAL; }
   if (B == 0) return NNMPC_OK;
   HIPCHK(hipSetDevice(h->device));
   const int G = h->seg_max;
+  const int ncol = out_kind == NNMPC_OUT_FIRST_MOVE ? h->nu : h->n;   // columns of the caller's u
+  h->ldu = ncol; h->nout = ncol;
   size_t e_tot0 = 0;
   if (h->profiling) { e_tot0 = ev_get(h); hipEventRecord(h->ev_pool[e_tot0], h->stream); }
-  // device scratch for outputs when the caller hands host pointers
+  // device staging for the outputs when the caller hands host pointers (owned by the handle, grown on demand)
   double* u_stage = nullptr; uint32_t* a_stage = nullptr; int32_t* s_stage = nullptr; int32_t* i_stage = nullptr;
   unsigned char* g_stage = nullptr;
   const int gmax = std::min(G, (int)B);
-  if (ptr_kind == NNMPC_HOST) {
-    HIPCHK(hipMalloc((void**)&u_stage, (size_t)gmax * h->n * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&a_stage, (size_t)gmax * h->words * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void**)&s_stage, (size_t)gmax * sizeof(int32_t)));
-    HIPCHK(hipMalloc((void**)&i_stage, (size_t)gmax * 2 * sizeof(int32_t)));
-    if (guess) HIPCHK(hipMalloc((void**)&g_stage, (size_t)gmax * h->n));
-  }
   int rc = 0;
+  if (ptr_kind == NNMPC_HOST) {
+    if (!rc) rc = scratch_get(h, nnmpc_qp::SC_U, &u_stage, (size_t)gmax * ncol * sizeof(double));
+    if (!rc && active) rc = scratch_get(h, nnmpc_qp::SC_ACT, &a_stage, (size_t)gmax * h->words * sizeof(uint32_t));
+    if (!rc && status) rc = scratch_get(h, nnmpc_qp::SC_ST, &s_stage, (size_t)gmax * sizeof(int32_t));
+    if (!rc && iters) rc = scratch_get(h, nnmpc_qp::SC_IT, &i_stage, (size_t)gmax * 2 * sizeof(int32_t));
+    if (!rc && guess) rc = scratch_get(h, nnmpc_qp::SC_GUESS, &g_stage, (size_t)gmax * h->n);
+  }
+  hipError_t he = hipSuccess;
+#define STEP_(x) do { if (!rc && he == hipSuccess) { he = (x); if (he != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(he)); rc = NNMPC_EHIP; } } } while (0)
   for (int b0 = 0; b0 < B && !rc; b0 += G) {
     const int nb = std::min(G, B - b0);
     const double *x0d, *lbd, *ubd;
     double* ud; uint32_t* ad; int32_t* sd; int32_t* idv;
     const unsigned char* gd = nullptr;
     if (ptr_kind == NNMPC_HOST) {
-      if (guess) { HIPCHK(hipMemcpyAsync(g_stage, guess + (size_t)b0 * h->n, (size_t)nb * h->n, hipMemcpyHostToDevice, h->stream)); gd = g_stage; }
-      HIPCHK(hipMemcpyAsync(h->in_stage, x0 + (size_t)b0 * h->n_aug, (size_t)nb * h->n_aug * 8, hipMemcpyHostToDevice, h->stream));
-      HIPCHK(hipMemcpyAsync(h->lb_d, lb + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
-      HIPCHK(hipMemcpyAsync(h->ub_d, ub + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
+      if (guess) { STEP_(hipMemcpyAsync(g_stage, guess + (size_t)b0 * h->n, (size_t)nb * h->n, hipMemcpyHostToDevice, h->stream)); gd = g_stage; }
+      STEP_(hipMemcpyAsync(h->in_stage, x0 + (size_t)b0 * h->n_aug, (size_t)nb * h->n_aug * 8, hipMemcpyHostToDevice, h->stream));
+      STEP_(hipMemcpyAsync(h->lb_d, lb + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
+      STEP_(hipMemcpyAsync(h->ub_d, ub + (size_t)b0 * h->nu, (size_t)nb * h->nu * 8, hipMemcpyHostToDevice, h->stream));
       x0d = h->in_stage; lbd = h->lb_d; ubd = h->ub_d;
       ud = u_stage; ad = active ? a_stage : nullptr; sd = status ? s_stage : nullptr; idv = iters ? i_stage : nullptr;
     } else {
       x0d = x0 + (size_t)b0 * h->n_aug; lbd = lb + (size_t)b0 * h->nu; ubd = ub + (size_t)b0 * h->nu;
       if (guess) gd = guess + (size_t)b0 * h->n;
-      ud = u + (size_t)b0 * h->n;
+      ud = u + (size_t)b0 * ncol;
       ad = active ? active + (size_t)b0 * h->words : nullptr;
       sd = status ? status + b0 : nullptr;
       idv = iters ? iters + 2 * (size_t)b0 : nullptr;
     }
+    if (rc) break;
     if (h->have_inverse && h->opts.method != 1) rc = solve_segment_asm(h, nb, x0d, lbd, ubd, gd, ud, ad, sd, idv);
     else rc = solve_segment(h, nb, x0d, lbd, ubd, gd, ud, ad, sd, idv);
     if (!rc && ptr_kind == NNMPC_HOST) {
-      HIPCHK(hipMemcpy(u + (size_t)b0 * h->n, u_stage, (size_t)nb * h->n * 8, hipMemcpyDeviceToHost));
-      if (active) HIPCHK(hipMemcpy(active + (size_t)b0 * h->words, a_stage, (size_t)nb * h->words * 4, hipMemcpyDeviceToHost));
-      if (status) HIPCHK(hipMemcpy(status + b0, s_stage, (size_t)nb * 4, hipMemcpyDeviceToHost));
-      if (iters) HIPCHK(hipMemcpy(iters + 2 * (size_t)b0, i_stage, (size_t)nb * 8, hipMemcpyDeviceToHost));
+      STEP_(hipMemcpy(u + (size_t)b0 * ncol, u_stage, (size_t)nb * ncol * 8, hipMemcpyDeviceToHost));
+      if (active) STEP_(hipMemcpy(active + (size_t)b0 * h->words, a_stage, (size_t)nb * h->words * 4, hipMemcpyDeviceToHost));
+      if (status) STEP_(hipMemcpy(status + b0, s_stage, (size_t)nb * 4, hipMemcpyDeviceToHost));
+      if (iters) STEP_(hipMemcpy(iters + 2 * (size_t)b0, i_stage, (size_t)nb * 8, hipMemcpyDeviceToHost));
     }
   }
-  if (u_stage) hipFree(u_stage);
-  if (a_stage) hipFree(a_stage);
-  if (s_stage) hipFree(s_stage);
-  if (i_stage) hipFree(i_stage);
-  if (g_stage) hipFree(g_stage);
+#undef STEP_
   if (h->profiling) {
     size_t e1 = ev_get(h);
     hipEventRecord(h->ev_pool[e1], h->stream);

@@ -1,13 +1,18 @@
 """Sample-parallel execution across the GPUs of one node.
 
-The reference's only parallelism is "N independent OS processes / cluster jobs,
-each on a contiguous slice of the scenario signal, results meeting on the file
-system" (lib/linearMPC.py:786-825, lib/controller_evaluation.py:273-295).  Here:
-one process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in
-the CPU tests), contiguous shards of the sample batch, no communication during
-the solves and ONE gather of the first moves at the end.
+The reference's only parallelism is "N independent OS processes / cluster jobs, each on a contiguous slice of the
+scenario signal, results meeting on the file system" (lib/linearMPC.py:786-825, lib/controller_evaluation.py:273-295).
+Here: one process per GPU, contiguous shards of the sample batch, no communication during the solves and ONE gather of
+the first moves at the end -- RCCL over xGMI through the library itself (``Comm`` = nnmpc_comm_*; no other GPU runtime
+binding is needed).  The same sharding contract runs over a ``torch.distributed`` group (gloo) in the CPU tests.
 """
+import ctypes as C
+import os
+import time
+
 import numpy as np
+
+from . import _lib
 
 
 def shard_bounds(total, rank, world):
@@ -18,8 +23,86 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def exchange_unique_id(rank, world, key, make_id, timeout_s=120.0):
+    """The 128-byte RCCL unique id of rank 0 reaches the other ranks through a file under /tmp (all ranks of a job are
+    on ONE node; ``key`` must be the same on every rank and unique to the job, e.g. MASTER_PORT + the launcher's pid)."""
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nnmpc_uid_{key}")
+    if rank == 0:
+        uid = make_id()
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)                       # atomic: readers see all 128 bytes or no file
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        time.sleep(0.01)
+    raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s} s")
+
+
+class Comm:
+    """RCCL communicator of one rank (nnmpc_comm_*).  The HIP device of this rank must be current (_lib.set_device)."""
+
+    def __init__(self, rank, world, key=None, uid=None):
+        lib = _lib.load()
+        self._lib, self.rank, self.world = lib, int(rank), int(world)
+        self._path = None
+        if uid is None:
+            def make():
+                buf = C.create_string_buffer(128)
+                _lib.check(lib.nnmpc_comm_unique_id(buf), "nnmpc_comm_unique_id")
+                return buf.raw
+            if world == 1:
+                uid = make()
+            else:
+                if key is None:
+                    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+                uid = exchange_unique_id(self.rank, self.world, key, make)
+                self._path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nnmpc_uid_{key}")
+        self._h = C.c_void_p()
+        _lib.check(lib.nnmpc_comm_init(C.byref(self._h), C.c_char_p(uid), self.rank, self.world), "nnmpc_comm_init")
+        if self._path and self.rank == 0:
+            self.barrier()                          # everybody has read the id: the file can go
+            try:
+                os.remove(self._path)
+            except OSError:
+                pass
+        elif self._path:
+            self.barrier()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nnmpc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def barrier(self):
+        _lib.check(self._lib.nnmpc_comm_barrier(self._h), "nnmpc_comm_barrier")
+
+    def allreduce_max(self, value):
+        v = C.c_double(float(value))
+        _lib.check(self._lib.nnmpc_comm_allreduce_max(self._h, C.byref(v)), "nnmpc_comm_allreduce_max")
+        return v.value
+
+    def gather_rows(self, local, rows, row_doubles, recv=None, root=0):
+        """``local``: device buffer (data_ptr()) with rows[rank] x row_doubles f64; ``recv``: device buffer with
+        sum(rows) x row_doubles on ``root``.  One gather over xGMI; ragged shards allowed."""
+        arr = (C.c_int64 * self.world)(*[int(r) for r in rows])
+        q = lambda a: None if a is None else C.c_void_p(a.data_ptr())
+        _lib.check(self._lib.nnmpc_comm_gather_rows(self._h, q(local), arr, int(row_doubles), q(recv), int(root)),
+                   "nnmpc_comm_gather_rows")
+
+
 def gather_rows(local, total, dst=0, group=None):
-    """Gather per-rank row blocks (torch tensors, shard_bounds order) on ``dst``.
+    """Gather per-rank row blocks (torch tensors, shard_bounds order) on ``dst`` over a torch.distributed group.
 
     Returns the (total, ...) tensor on dst, None elsewhere.  One collective.
     """
@@ -39,18 +122,30 @@ def gather_rows(local, total, dst=0, group=None):
     return None
 
 
-def solve_sharded(solve_local, X0, lb, ub, nu, dst=0, group=None, device=None):
+def solve_sharded(solve_local, X0, lb, ub, nu, dst=0, group=None, device=None, comm=None):
     """Shard (X0, lb, ub) rows over the ranks, solve locally, gather the first moves on dst.
 
-    ``solve_local(x0, lb, ub) -> u (b, n)`` numpy in/out (e.g. BatchedBoxQP.solve_batch(...)['u']).
+    ``solve_local(x0, lb, ub) -> u (b, n) or (b, nu)`` numpy in/out (e.g. BatchedBoxQP.solve_batch(...)['u']).
+    With ``comm`` (a ``Comm``) the gather is the library's RCCL one and the result is a numpy array on dst;
+    otherwise a torch.distributed group (gloo in the CPU tests) carries it and a tensor comes back.
     """
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    else:
+        import torch
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
     total = X0.shape[0]
     lo, hi = shard_bounds(total, rank, world)
     u = solve_local(X0[lo:hi], lb[lo:hi], ub[lo:hi])
-    first = torch.from_numpy(np.ascontiguousarray(u[:, :nu]))
+    first = np.ascontiguousarray(u[:, :nu])
+    if comm is not None:
+        rows = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+        send = _lib.DeviceArray.from_host(first) if first.size else None
+        recv = _lib.DeviceArray((total, nu), np.float64) if rank == dst else None
+        comm.gather_rows(send, rows, nu, recv, root=dst)
+        return recv.to_host() if rank == dst else None
+    first = torch.from_numpy(first)
     if device is not None:
         first = first.to(device)
     return gather_rows(first, total, dst=dst, group=group)

@@ -10,16 +10,21 @@ changes is where the arithmetic of the hot path runs:
   the condensed QP to the HIP library (``qp.BatchedBoxQP``); the additive
   ``solve_batch`` entry point solves B independent (x0, ulb, uub) per call.
 * ``OfflineSimulator.generate_data`` / ``simulate_offline`` (:803-880) advance
-  all chains of a task in lock-step, one batched GPU regulator solve per step,
-  instead of one OS process per chain.
+  all chains of a task in lock-step on the device (``chain.DeviceChains``): chain
+  state, target pairs and recorded trajectories stay in HBM, one batched regulator
+  solve per step, instead of one OS process per chain.
+* ``TargetSelector.solve`` (:298-311 -> cvxopt.solvers.qp with equalities): the
+  distinct (ysp, dhat) pairs of a task are solved once, batched, on the GPU
+  (``target.BatchedTargetSelector``).
 * the condensed matrices are built by recursion (``condense.py``) instead of
   the dense block-diagonal stacks (:397-474).
 
-Kalman filter, plant simulator and the small target-selector QP (n = Nx + Nu)
-stay on the host in fp64: they are not on the hot path.
+Kalman filter and plant simulator stay on the host in fp64: they are not on the
+hot path.
 """
 import sys
 import time
+import warnings
 
 import numpy as np
 import scipy.linalg
@@ -108,18 +113,29 @@ class KalmanFilter:
 
 
 class TargetSelector:
-    """Steady-state target QP (reference :178-319): same (P, q, G, h, A, b) as
-    the reference builds; solved on the host in fp64 (n = Nx + Nu, not the hot path)."""
+    """Steady-state target QP (reference :178-319): same (P, q, G, h, A, b) as the reference builds.
 
-    def __init__(self, *, A, B, C, H, Bd, Cd, usp, Rs, Qs, ulb, uub, ylb=None, yub=None):
+    ``backend="hip"`` (default): equalities eliminated once on the host, the distinct (ysp, dhat) pairs of a
+    batch solved on the GPU (``target.BatchedTargetSelector``); needs [I - A; H C] of full column rank and the
+    input box only.  ``backend="host"``: the full-space problem in the small fp64 host solver (``host_qp``), one
+    at a time -- explicit opt-in (output constraints ylb/yub, rank-deficient plants), never a silent fallback.
+    """
+
+    def __init__(self, *, A, B, C, H, Bd, Cd, usp, Rs, Qs, ulb, uub, ylb=None, yub=None, backend="hip"):
         self.A, self.B, self.C, self.H, self.Bd, self.Cd, self.Rs, self.Qs = A, B, C, H, Bd, Cd, Rs, Qs
         self.Nx, self.Nu, self.Ny = A.shape[0], B.shape[1], C.shape[0]
         self.Nd, self.Nz = Bd.shape[1], H.shape[0]
         self.usp = usp
         self.ysp, self.dhats, self.xs, self.us = [], [], [], []
         self.ulb, self.uub, self.ylb, self.yub = ulb, uub, ylb, yub
+        if backend not in ("hip", "host"):
+            raise ValueError("backend must be 'hip' or 'host'")
+        if backend == "hip" and (ylb is not None or yub is not None):
+            raise NotImplementedError("output constraints (ylb, yub) are only handled by backend='host'")
+        self.backend = backend
         self._setup_fixed_matrices()
         self._cache = {}
+        self._batched = None
 
     def _setup_fixed_matrices(self):
         Nx, Nu, Ny, Nz = self.Nx, self.Nu, self.Ny, self.Nz
@@ -145,13 +161,42 @@ class TargetSelector:
         b = self.tb @ np.vstack((ysp, dhats))
         return (q, h, b)
 
+    def _device(self):
+        if self._batched is None:
+            from .target import BatchedTargetSelector
+            self._batched = BatchedTargetSelector(self.A, self.B, self.C, self.H, self.Bd, self.Cd, self.Qs, self.Rs,
+                                                  self.usp, self.ulb, self.uub)
+        return self._batched
+
+    def solve_batch(self, Ysp, Dhat):
+        """Rows (ysp, dhat) -> (Xs (M, Nx), Us (M, Nu)).  Identical rows (piecewise-constant PRBS signals: a few
+        thousand distinct pairs in 357 600 CDU steps, cdu_parameters.py:135-143) are solved once."""
+        Ysp = np.asarray(Ysp, float).reshape(-1, self.Ny)
+        Dhat = np.asarray(Dhat, float).reshape(-1, self.Nd)
+        if self.backend == "host":
+            key = np.concatenate((Ysp, Dhat), axis=1)
+            uniq, inv = np.unique(key, axis=0, return_inverse=True)
+            sol = np.empty((uniq.shape[0], self.Nx + self.Nu))
+            for i, row in enumerate(uniq):
+                (q, h, b) = self._setup_changing_matrices(row[:self.Ny, None], row[self.Ny:, None])
+                sol[i] = solve_small_qp(self.P, q, self.G, h, self.tA, b)
+            sol = sol[np.ravel(inv)]
+            return sol[:, :self.Nx], sol[:, self.Nx:]
+        Xs, Us, st = self._device().solve_batch(Ysp, Dhat)
+        if (st != 0).any():
+            bad = int(np.flatnonzero(st != 0)[0])
+            raise ArithmeticError(f"target selector: {int((st != 0).sum())} of {st.size} problems not solved (first: row {bad}, "
+                                  f"status {int(st[bad])}): no steady state reaches that setpoint inside the input bounds "
+                                  "(the equalities restricted to the free inputs lose rank)")
+        return Xs, Us
+
     def solve(self, ysp, dhats):
-        """(xs, us) for one (ysp, dhat).  Identical consecutive inputs (piecewise-constant
-        PRBS signals) are answered from a one-entry cache."""
+        """(xs, us) for one (ysp, dhat), reference signature (:298-311).  Identical consecutive inputs
+        (piecewise-constant signals) are answered from a one-entry cache."""
         key = (ysp.tobytes(), dhats.tobytes())
         if key not in self._cache:
-            (q, h, b) = self._setup_changing_matrices(ysp, dhats)
-            self._cache = {key: solve_small_qp(self.P, q, self.G, h, self.tA, b)}
+            Xs, Us = self.solve_batch(ysp.reshape(1, -1), dhats.reshape(1, -1))
+            self._cache = {key: np.concatenate((Xs[0], Us[0]))}
         (xs, us) = np.split(self._cache[key].reshape(-1, 1), [self.Nx])
         self.xs.append(xs); self.us.append(us); self.ysp.append(ysp); self.dhats.append(dhats)
         return (xs, us)
@@ -172,6 +217,9 @@ class DenseQPRegulator:
         (self.P, self.tq) = condense.condense(self.A, self.B, self.Q, self.R, self.M, self.Pf, N)
         self._max_batch = max_batch
         self._opts = dict(solver_options or {})
+        # this class solves at most max_batch problems per call (one per call from the reference's own loops): size the
+        # active-set workspace for that, not for a quarter of the HBM (qp.BatchedBoxQP's default for bulk batches)
+        self._opts.setdefault("seg_max", max(128, int(max_batch)))
         self._qp = None
         self.x0, self.useq = [], []
         self.last_info = None
@@ -246,16 +294,20 @@ class DenseQPRegulator:
         ub = self.uub if uub is None else uub
         out = self._solver().solve_batch(np.asarray(X0, float).reshape(-1, self.Nx),
                                          np.asarray(lb, float).reshape(-1, self.Nu),
-                                         np.asarray(ub, float).reshape(-1, self.Nu), guess=guess)
+                                         np.asarray(ub, float).reshape(-1, self.Nu), guess=guess,
+                                         first_move_only=first_move_only)
         U = out.pop("u")
         self.last_info = out
-        return (U[:, :self.Nu] if first_move_only else U), out
+        return U, out
 
     def solve(self, x0):
         """One problem, reference signature: x0 (n_aug, 1) -> useq (N*Nu, 1)  (reference :495-512)."""
         U, info = self.solve_batch(x0.reshape(1, -1), self.ulb.reshape(1, -1), self.uub.reshape(1, -1))
-        if info["status"][0] == 2:
-            raise ArithmeticError("regulator QP: numerical failure in the KKT factorisation")
+        if info["status"][0] == 2:                 # cvxopt raises on a singular KKT matrix / invalid data
+            raise ArithmeticError("regulator QP: numerical failure (NaN / Inf in the data, lb > ub, or a non-positive pivot)")
+        if info["status"][0] != 0:                 # cvxopt would return status 'unknown' (the reference does not look at it)
+            warnings.warn("regulator QP: iteration budget exhausted, the returned sequence is NOT certified optimal",
+                          RuntimeWarning)
         useq = U.reshape(-1, 1)
         self._save_data(x0, useq)
         return useq
@@ -390,44 +442,79 @@ def _save_training_data(dictionary, filename):
         return filename + ".npz"
 
 
+def _target_pairs(target_selectors, setpoints, disturbances):
+    """(Xs (T, nc, Nx), Us (T, nc, Nu)) for every chain and step (reference :851, one QP per step and chain).
+
+    Chains whose selectors are TargetSelector objects go through ONE deduplicated batched solve (all chains of a task
+    share the plant, so the first selector's matrices serve them all); anything else with a ``solve(ysp, dhat)``
+    method is asked step by step."""
+    nc, T = len(setpoints), setpoints[0].shape[0]
+    if all(isinstance(ts, TargetSelector) for ts in target_selectors):
+        Ysp = np.stack([np.asarray(setpoints[c], float) for c in range(nc)], axis=1)       # (T, nc, Ny)
+        Dh = np.stack([np.asarray(disturbances[c], float) for c in range(nc)], axis=1)     # (T, nc, Nd)
+        Xs, Us = target_selectors[0].solve_batch(Ysp.reshape(T * nc, -1), Dh.reshape(T * nc, -1))
+        return Xs.reshape(T, nc, -1), Us.reshape(T, nc, -1)
+    first = target_selectors[0].solve(setpoints[0][0][:, None], disturbances[0][0][:, None])
+    Xs, Us = np.empty((T, nc, first[0].size)), np.empty((T, nc, first[1].size))
+    for c in range(nc):
+        for t in range(T):
+            (xs, us) = LinearMPCController.get_target_pair(target_selectors[c], setpoints[c][t][:, None],
+                                                           disturbances[c][t][:, None])
+            Xs[t, c], Us[t, c] = xs[:, 0], us[:, 0]
+    return Xs, Us
+
+
 def simulate_chains(x0, uprev0, A, B, Bd, regulator, ulb, uub, target_selectors, setpoints, disturbances,
-                    warm_start=True):
+                    warm_start=True, device_resident=True, allow_uncertified=False):
     """Lock-step closed-loop chains: chain c follows setpoints[c] (T, Ny), disturbances[c] (T, Nd).
 
-    Per step: target pair per chain (host), ONE batched regulator solve for all chains (GPU),
-    model step x+ = A x + B u + Bd d.  Same recurrences and outputs as the reference's
-    simulate_offline (:845-872), which runs one chain per OS process.  With ``warm_start`` the
-    active set of step t, shifted by one stage, seeds the solve of step t+1 (consecutive QPs of a
-    chain differ little); results are identical either way (every solve is KKT-certified).
+    Target pairs of all chains and steps first (deduplicated, batched), then per step ONE batched regulator solve for
+    all chains and the model step x+ = A x + B u + Bd d.  Same recurrences and outputs as the reference's
+    simulate_offline (:845-872), which runs one chain per OS process.  ``device_resident`` (default): the whole loop runs
+    in the library (nnmpc_chain_run) with the chain state and the records in HBM; otherwise the loop is driven from
+    here, one host round trip per step (also reports ``factorizations``).  With ``warm_start`` the active set of step t,
+    shifted by one stage, seeds the solve of step t+1; results are identical either way (every solve is KKT-certified).
+    A solve that ends uncertified (status != 0) raises unless ``allow_uncertified``; ``status`` is part of the result.
     """
     nc = len(setpoints)
     T = setpoints[0].shape[0]
     Nx, Nu = B.shape
-    X = np.tile(x0.T, (nc, 1))
-    Uprev = np.tile(uprev0.T, (nc, 1))
-    out = dict(x=np.empty((nc, T, Nx)), uprev=np.empty((nc, T, Nu)), xs=np.empty((nc, T, Nx)),
-               us=np.empty((nc, T, Nu)), u=np.empty((nc, T, Nu)))
-    status = np.zeros((nc, T), np.int32)
-    nfac = np.zeros((nc, T), np.int32)
-    guess = None
-    for t in range(T):
-        Xs, Us = np.empty((nc, Nx)), np.empty((nc, Nu))
-        for c in range(nc):
-            (xs, us) = LinearMPCController.get_target_pair(target_selectors[c], setpoints[c][t][:, None],
-                                                           disturbances[c][t][:, None])
-            Xs[c], Us[c] = xs[:, 0], us[:, 0]
-        U, info = LinearMPCController.get_control_sequence_batch(regulator, X, Uprev, Xs, Us, ulb, uub, guess=guess)
-        status[:, t] = info["status"]
-        nfac[:, t] = info["factorizations"]
-        if warm_start:
-            st = regulator._solver().active_to_state(info["active"])      # (nc, N*Nu)
-            guess = np.concatenate((st[:, Nu:], st[:, -Nu:]), axis=1)      # shift one stage, repeat the last
-        out["x"][:, t], out["uprev"][:, t], out["xs"][:, t], out["us"][:, t], out["u"][:, t] = X, Uprev, Xs, Us, U
-        D = np.stack([disturbances[c][t] for c in range(nc)])
-        X = X @ A.T + U @ B.T + D @ Bd.T
-        Uprev = U
-    out["status"] = status
-    out["factorizations"] = nfac
+    Xs, Us = _target_pairs(target_selectors, setpoints, disturbances)
+    D = np.stack([np.asarray(disturbances[c], float) for c in range(nc)], axis=1)             # (T, nc, Nd)
+    if device_resident:
+        from .chain import DeviceChains
+        ch = DeviceChains(regulator._solver(), nc, A, B, Bd, ulb, uub, x0, uprev0)
+        rec = ch.run(Xs, Us, D, warm_start=warm_start)
+        ch.close()
+        out = {k: np.ascontiguousarray(np.swapaxes(rec[k], 0, 1)) for k in ("x", "uprev", "u")}
+        out["xs"], out["us"] = np.ascontiguousarray(np.swapaxes(Xs, 0, 1)), np.ascontiguousarray(np.swapaxes(Us, 0, 1))
+        out["status"] = np.ascontiguousarray(rec["status"].T)
+        out["factorizations"] = np.zeros((nc, T), np.int32)
+    else:
+        X = np.tile(x0.T, (nc, 1))
+        Uprev = np.tile(uprev0.T, (nc, 1))
+        out = dict(x=np.empty((nc, T, Nx)), uprev=np.empty((nc, T, Nu)), xs=np.empty((nc, T, Nx)),
+                   us=np.empty((nc, T, Nu)), u=np.empty((nc, T, Nu)))
+        status = np.zeros((nc, T), np.int32)
+        nfac = np.zeros((nc, T), np.int32)
+        guess = None
+        for t in range(T):
+            U, info = LinearMPCController.get_control_sequence_batch(regulator, X, Uprev, Xs[t], Us[t], ulb, uub, guess=guess)
+            status[:, t] = info["status"]
+            nfac[:, t] = info["factorizations"]
+            if warm_start:
+                st = regulator._solver().active_to_state(info["active"])      # (nc, N*Nu)
+                guess = np.concatenate((st[:, Nu:], st[:, -Nu:]), axis=1)      # shift one stage, repeat the last
+            out["x"][:, t], out["uprev"][:, t], out["xs"][:, t], out["us"][:, t], out["u"][:, t] = X, Uprev, Xs[t], Us[t], U
+            X = X @ A.T + U @ B.T + D[t] @ Bd.T
+            Uprev = U
+        out["status"] = status
+        out["factorizations"] = nfac
+    if not allow_uncertified and (out["status"] != 0).any():
+        c, t = np.argwhere(out["status"] != 0)[0]
+        raise RuntimeError(f"simulate_chains: {int((out['status'] != 0).sum())} regulator solve(s) not certified optimal "
+                           f"(first: chain {c}, step {t}, status {int(out['status'][c, t])}); the trajectories after that "
+                           "step are not the MPC law's -- pass allow_uncertified=True to get them anyway")
     return out
 
 
@@ -436,7 +523,7 @@ def simulate_offline(task_number, process_number, data_filename, x0, uprev0, A, 
     """One chain, reference signature (:827-880); runs through the batched driver with B = 1."""
     t0 = time.time()
     res = simulate_chains(x0, uprev0, A, B, Bd, regulator, ulb, uub, [target_selector], [setpoints], [disturbances])
-    data = {k: res[k][0] for k in ("x", "uprev", "xs", "us", "u")}
+    data = {k: res[k][0] for k in ("x", "uprev", "xs", "us", "u", "status")}
     data["data_gen_time"] = time.time() - t0
     return _save_training_data(data, str(task_number) + '-' + str(process_number) + '-' + data_filename)
 
@@ -479,7 +566,7 @@ class OfflineSimulator:
         dt = time.time() - t0
         files = []
         for proc in range(self.num_process_per_task):
-            data = {k: res[k][proc] for k in ("x", "uprev", "xs", "us", "u")}
+            data = {k: res[k][proc] for k in ("x", "uprev", "xs", "us", "u", "status")}   # status: 0 = certified optimal
             data["data_gen_time"] = dt
             files.append(_save_training_data(data, str(task_number) + '-' + str(proc) + '-' + data_filename))
         return files

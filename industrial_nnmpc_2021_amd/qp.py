@@ -67,10 +67,19 @@ class BatchedBoxQP:
                                        P.ctypes.data_as(C.c_void_p), tq.ctypes.data_as(C.c_void_p),
                                        kp, C.byref(opts)), "nnmpc_qp_create")
         self._lib = lib
+        self.have_inverse = False
         if Hinv is not None:
             Hinv = np.ascontiguousarray(Hinv, dtype=np.float64)
-            _lib.check(lib.nnmpc_qp_set_inverse(self._h, Hinv.ctypes.data_as(C.c_void_p),
-                                                Kunc.ctypes.data_as(C.c_void_p)), "nnmpc_qp_set_inverse")
+            rc = lib.nnmpc_qp_set_inverse(self._h, Hinv.ctypes.data_as(C.c_void_p), Kunc.ctypes.data_as(C.c_void_p))
+            if rc == _lib.EINVAL and meth == 0:
+                # the fp64 inverse of an ill-conditioned P missed the library's |P Pinv - I| check: the active-set
+                # pass cannot be certified with it, the PDIP path needs no inverse -- method "auto" goes on without
+                import warnings
+                warnings.warn("BatchedBoxQP: " + lib.nnmpc_last_error().decode(errors="replace") +
+                              " -- continuing with the PDIP path only", RuntimeWarning)
+            else:
+                _lib.check(rc, "nnmpc_qp_set_inverse")
+                self.have_inverse = True
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -79,18 +88,19 @@ class BatchedBoxQP:
 
     __del__ = close
 
-    def solve_batch(self, x0, lb, ub, guess=None):
+    def solve_batch(self, x0, lb, ub, guess=None, first_move_only=False):
         """numpy in / numpy out.  x0 (B, n_aug), lb/ub (B, nu) or (nu,); guess: optional (B, n) uint8
         active-set estimate (0 free, 1 upper, 2 lower) that replaces the PDIP phase (warm start).
 
-        Returns dict(u (B, n), active (B, 2n) bool in the row order of the
-        reference's G, status (B,), ipm_iters (B,), factorizations (B,)).
+        Returns dict(u (B, n) -- or (B, nu) with first_move_only, all the reference keeps of a solve in its
+        simulation loops (lib/linearMPC.py:856) --, active (B, 2n) bool in the row order of the reference's G,
+        status (B,), ipm_iters (B,), factorizations (B,)).
         """
         x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, self.n_aug)
         B = x0.shape[0]
         lb = np.ascontiguousarray(np.broadcast_to(np.asarray(lb, np.float64).reshape(-1, self.nu), (B, self.nu)))
         ub = np.ascontiguousarray(np.broadcast_to(np.asarray(ub, np.float64).reshape(-1, self.nu), (B, self.nu)))
-        u = np.empty((B, self.n))
+        u = np.empty((B, self.nu if first_move_only else self.n))
         act = np.zeros((B, self.words), np.uint32)
         status = np.empty(B, np.int32)
         iters = np.empty((B, 2), np.int32)
@@ -99,9 +109,9 @@ class BatchedBoxQP:
             guess = np.ascontiguousarray(guess, dtype=np.uint8).reshape(B, self.n)
             gp = guess.ctypes.data_as(C.c_void_p)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(self._lib.nnmpc_qp_solve_batch_warm(
-            self._h, B, p(x0), p(lb), p(ub), gp, p(u), p(act), p(status), p(iters), _lib.HOST),
-            "nnmpc_qp_solve_batch")
+        _lib.check(self._lib.nnmpc_qp_solve_batch_ex(
+            self._h, B, p(x0), p(lb), p(ub), gp, p(u), p(act), p(status), p(iters), _lib.HOST,
+            _lib.OUT_FIRST_MOVE if first_move_only else _lib.OUT_SEQUENCE), "nnmpc_qp_solve_batch_ex")
         bits = np.unpackbits(act.view(np.uint8), axis=1, bitorder="little")[:, :2 * self.n].astype(bool)
         return dict(u=u, active=bits, status=status, ipm_iters=iters[:, 0], factorizations=iters[:, 1])
 
@@ -111,10 +121,14 @@ class BatchedBoxQP:
         k, c = np.arange(n) // nu, np.arange(n) % nu
         return (active[:, k * 2 * nu + c].astype(np.uint8) + 2 * active[:, k * 2 * nu + nu + c].astype(np.uint8))
 
-    def solve_batch_device(self, B, x0, lb, ub, u, active=None, status=None, iters=None):
-        """HBM-resident buffers (objects with data_ptr(), e.g. torch CUDA tensors, f64/u32/i32)."""
-        ptrs = [(_ptr(a)[0] if a is not None else None) for a in (x0, lb, ub, u, active, status, iters)]
-        _lib.check(self._lib.nnmpc_qp_solve_batch(self._h, B, *ptrs, _lib.DEVICE), "nnmpc_qp_solve_batch")
+    def solve_batch_device(self, B, x0, lb, ub, u, active=None, status=None, iters=None, guess=None,
+                           first_move_only=False):
+        """HBM-resident buffers (objects with data_ptr(): _lib.DeviceArray, torch CUDA tensors; f64/u32/i32/u8).
+        u is (B, n), or (B, nu) with first_move_only."""
+        q = lambda a: (_ptr(a)[0] if a is not None else None)
+        _lib.check(self._lib.nnmpc_qp_solve_batch_ex(
+            self._h, B, q(x0), q(lb), q(ub), q(guess), q(u), q(active), q(status), q(iters), _lib.DEVICE,
+            _lib.OUT_FIRST_MOVE if first_move_only else _lib.OUT_SEQUENCE), "nnmpc_qp_solve_batch_ex")
 
     def set_profiling(self, on=True):
         _lib.check(self._lib.nnmpc_qp_set_profiling(self._h, int(on)), "nnmpc_qp_set_profiling")

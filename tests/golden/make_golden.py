@@ -14,6 +14,10 @@ small .npz files.  Only data is stored -- no reference source travels.
                          injected at the cvxopt.solvers.qp seam
   nn_<case>.npz          reference NeuralNetworkController._get_control_input outputs
   prbs.npz               reference sample_prbs_like outputs
+  target.npz             reference TargetSelector.solve (oracle at the qp seam) on seeded (ysp, dhat) pairs, each
+                         cross-checked at generation time against scipy's trust-constr on the full-space problem
+  closed_loop.npz        reference online_simulation with LinearMPCController and NeuralNetworkController on a
+                         seeded plant (np.random.seed for the measurement noise): y, u, x, xhat, average stage costs
 """
 import io
 import os
@@ -74,6 +78,93 @@ CASES = {  # name: (Nx, Nu, Ny, N, rho, qweight, sweight)
     "unstable_s0": (6, 2, 3, 8, 1.03, 2.0, 0.0),     # re-parameterised branch
     "unstable_s1": (4, 2, 4, 7, 1.05, 10.0, 0.1),
 }
+
+
+def make_target(ref):
+    """TargetSelector.solve (lib/linearMPC.py:298-311) on seeded pairs; only pairs whose optimum an INDEPENDENT solver
+    (scipy trust-constr on the full-space problem, equality + bound constraints) confirms are kept."""
+    from scipy.optimize import minimize, LinearConstraint, Bounds
+    rng = np.random.default_rng(21)
+    Nx, Nu, Ny, Nz, Nd = 12, 5, 6, 2, 3
+    A, B, C = plant(rng, Nx, Nu, Ny, 0.9)
+    H = np.eye(Nz, Ny)
+    Bd = rng.standard_normal((Nx, Nd)) / np.sqrt(Nx); Cd = 0.1 * rng.standard_normal((Ny, Nd))
+    Qs, Rs, usp = np.eye(Ny), 1e-2 * np.eye(Nu), 0.1 * rng.standard_normal((Nu, 1))
+    ulb, uub = -np.ones((Nu, 1)), np.ones((Nu, 1))
+    ts = ref.TargetSelector(A=A, B=B, C=C, H=H, Bd=Bd, Cd=Cd, usp=usp, Rs=Rs, Qs=Qs, ulb=ulb, uub=uub)
+    ysp_l, d_l, xs_l, us_l = [], [], [], []
+    for t in range(400):
+        if len(ysp_l) >= 24:
+            break
+        ysp = rng.uniform(0.3, 1.2) * rng.standard_normal((Ny, 1)); d = rng.standard_normal((Nd, 1))
+        try:
+            xs, us = ts.solve(ysp, d)
+        except np.linalg.LinAlgError:
+            continue                                          # no steady state inside the input box
+        (q, h, b) = ts._setup_changing_matrices(ysp, d)
+        z0 = np.concatenate((xs, us)).ravel()
+        f = lambda z: 0.5 * z @ (ts.P @ z) + q.ravel() @ z
+        g = lambda z: ts.P @ z + q.ravel()
+        res = minimize(f, np.zeros(Nx + Nu), jac=g, hess=lambda z: ts.P, method="trust-constr",
+                       constraints=[LinearConstraint(ts.tA, b.ravel(), b.ravel())],
+                       bounds=Bounds(np.concatenate((-np.inf * np.ones(Nx), ulb.ravel())), np.concatenate((np.inf * np.ones(Nx), uub.ravel()))),
+                       options=dict(xtol=1e-12, gtol=1e-12, barrier_tol=1e-12, maxiter=3000))
+        if np.abs(res.x - z0).max() > 2e-6 or np.abs(ts.tA @ z0 - b.ravel()).max() > 1e-9:
+            continue
+        ysp_l.append(ysp[:, 0]); d_l.append(d[:, 0]); xs_l.append(xs[:, 0]); us_l.append(us[:, 0])
+    ysp_l, d_l, xs_l, us_l = map(np.array, (ysp_l, d_l, xs_l, us_l))
+    nsat = (np.abs(np.abs(us_l) - 1.0) < 1e-9).sum(axis=1)
+    np.savez_compressed(os.path.join(HERE, "target.npz"), A=A, B=B, C=C, H=H, Bd=Bd, Cd=Cd, Qs=Qs, Rs=Rs, usp=usp, ulb=ulb, uub=uub,
+                        ysp=ysp_l, dhat=d_l, xs=xs_l, us=us_l)
+    print("target", ysp_l.shape[0], "pairs, saturated inputs per pair:", np.bincount(nsat))
+
+
+def make_closed_loop(ref, ce):
+    """online_simulation (lib/linearMPC.py:703-718) with the QP controller (:519-701) and with the NN controller
+    (lib/controller_evaluation.py:780-892) -- the oracle solves the QPs at the cvxopt seam."""
+    import tempfile
+    rng = np.random.default_rng(31)
+    Nx, Nu, Ny, Nd, N, Nsim = 6, 2, 3, 2, 8, 30
+    A, B, C = plant(rng, Nx, Nu, Ny, 0.9)
+    Bd = rng.standard_normal((Nx, Nd)) / np.sqrt(Nx); Cd = np.zeros((Ny, Nd))
+    H = np.eye(1, Ny)
+    Q, R, S = 2.0 * C.T @ C, 0.1 * np.eye(Nu), 0.05 * np.eye(Nu)
+    Rs, Qs = 1e-3 * np.eye(Nu), np.eye(Ny)
+    Qwx, Qwd, Rv = 1e-4 * np.eye(Nx), 1e-2 * np.eye(Nd), 1e-4 * np.eye(Ny)
+    ulb, uub = -np.ones((Nu, 1)), np.ones((Nu, 1))
+    setpoints = np.repeat(rng.uniform(-1.5, 1.5, (3, Ny)), Nsim // 3 + 1, axis=0)[:Nsim]
+    disturbances = np.repeat(rng.uniform(-1, 1, (2, Nd)), Nsim // 2 + 1, axis=0)[:Nsim]
+    common = dict(A=A, B=B, C=C, H=H, Qwx=Qwx, Qwd=Qwd, Rv=Rv, xprior=np.zeros((Nx, 1)), dprior=np.zeros((Nd, 1)),
+                  Rs=Rs, Qs=Qs, Bd=Bd, Cd=Cd, usp=np.zeros((Nu, 1)), uprev=np.zeros((Nu, 1)), Q=Q, R=R, S=S, ulb=ulb, uub=uub)
+    # NN weights: small, so that the loop stays the plant's own stable dynamics plus a bounded input
+    dims = [2 * Nx + 2 * Nu, 16, 16, Nu]
+    W = []
+    for i in range(3):
+        W.append(0.3 * rng.standard_normal((dims[i], dims[i + 1])) / np.sqrt(dims[i]))
+        if i < 2:
+            W.append(0.1 * rng.standard_normal(dims[i + 1]))
+    xscale = rng.uniform(0.5, 2.0, Nx)
+    out = {}
+    old = sys.stdout
+    for name in ("mpc", "nn"):
+        np.random.seed(17)
+        pl = ref.LinearPlantSimulator(A=A, B=B, C=C, Bp=Bd, Rv=Rv, sample_time=1.0, x0=np.zeros((Nx, 1)))
+        if name == "mpc":
+            ctl = ref.LinearMPCController(N=N, **common)
+        else:
+            ctl = ce.NeuralNetworkController(regulator_weights=W, xscale=xscale, nnwithuprev=True, **common)
+        with tempfile.NamedTemporaryFile("w") as tf:
+            try:
+                ref.online_simulation(pl, ctl, setpoints=setpoints, disturbances=disturbances, Nsim=Nsim, stdout_filename=tf.name)
+            finally:
+                sys.stdout.close(); sys.stdout = old
+        out[f"{name}_y"] = np.array(pl.y)[:, :, 0]; out[f"{name}_u"] = np.array(pl.u)[:, :, 0]; out[f"{name}_x"] = np.array(pl.x)[:, :, 0]
+        out[f"{name}_xhat"] = np.array(ctl.filter.xhat)[:, :, 0]
+        out[f"{name}_avg_cost"] = np.array(ctl.average_stage_costs).ravel()
+        print("closed loop", name, "max |u|", np.abs(out[f"{name}_u"]).max(), "final avg cost", out[f"{name}_avg_cost"][-1])
+    np.savez_compressed(os.path.join(HERE, "closed_loop.npz"), A=A, B=B, C=C, H=H, Bd=Bd, Cd=Cd, Q=Q, R=R, S=S, Rs=Rs, Qs=Qs,
+                        Qwx=Qwx, Qwd=Qwd, Rv=Rv, ulb=ulb, uub=uub, N=N, Nsim=Nsim, setpoints=setpoints, disturbances=disturbances,
+                        xscale=xscale, nW=len(W), **{f"W{i}": w for i, w in enumerate(W)}, **out)
 
 
 def main():
@@ -166,6 +257,9 @@ def main():
                             ulb=ulb, uub=uub, x=x, xs=xs, us=us, uprev=uprev, u=np.array(u),
                             **{f"W{i}": w for i, w in enumerate(W)}, nW=len(W))
         print("nn", name, np.array(u).shape)
+
+    make_target(ref)
+    make_closed_loop(ref, ce)
 
     # ---- PRBS sampler (lib/controller_evaluation.py:21-47)
     sig = ce.sample_prbs_like(num_change=6, num_steps=60, lb=np.array([[-1.], [0.]]), ub=np.array([[1.], [2.]]),

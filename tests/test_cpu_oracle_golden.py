@@ -114,7 +114,7 @@ def test_target_selector_and_split_match_reference_chain(golden_dir):
     g = _load(golden_dir, "chain.npz")
     nu = g["B"].shape[1]
     ts = lm.TargetSelector(A=g["A"], B=g["B"], C=g["C"], H=g["H"], Bd=g["Bd"], Cd=g["Cd"], usp=np.zeros((nu, 1)),
-                           Rs=g["Rs"], Qs=g["Qs"], ulb=g["ulb"], uub=g["uub"])
+                           Rs=g["Rs"], Qs=g["Qs"], ulb=g["ulb"], uub=g["uub"], backend="host")   # (the hip backend: test_chain_target_gpu.py)
     T = g["x_0"].shape[0]
     for task in range(2):
         sp = g["setpoints"][task * T:(task + 1) * T]
