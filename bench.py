@@ -153,7 +153,7 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
                              "sample": f"{d1} problem(s), one process, 1 BLAS thread, {t1:.1f} s"}
         import multiprocessing as mp
         nproc = min(os.cpu_count() or 1, 16 if workload == "cdu" else 64)
-        per = 1 if workload == "cdu" else 8
+        per = 1 if workload == "cdu" else 4
         jobs = [(P, tq, nu, N, x0[i * per:(i + 1) * per], lb[i * per:(i + 1) * per], ub[i * per:(i + 1) * per], 1e9)
                 for i in range(nproc) if (i + 1) * per <= x0.shape[0]]
         t2 = time.time()
@@ -362,17 +362,45 @@ def parity_leg(h, k_oracle, k_kkt):
            "wrong_sign_multipliers": int((np.where(au, -G, 1) <= 0).sum() + (np.where(al, G, 1) <= 0).sum())}
     errs, ham, sizes = [], 0, []
     pos = {r: i for i, r in enumerate(rows_k)}
-    for r in rows_o:
-        info = {"nu": nu}
-        xe = oqp.solve_exact_box(Ps, tq @ x0_h[r], np.tile(lb_h[r], N), np.tile(ub_h[r], N), info=info)
+    # the oracle solves are independent: a pool of forked workers (they inherit P and never touch the GPU), a few BLAS threads each
+    global _ORACLE_JOB
+    _ORACLE_JOB = (Ps, tq, nu, N, x0_h, lb_h, ub_h)
+    nw = max(1, min(16, len(rows_o), (os.cpu_count() or 1) // 4))
+    if nw > 1 and n >= 1024:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nw) as pool:
+            sols = pool.map(_oracle_row, [(int(r), max(1, (os.cpu_count() or 1) // (2 * nw))) for r in rows_o])
+    else:
+        sols = [_oracle_row((int(r), 0)) for r in rows_o]
+    for r, (xe, active) in zip(rows_o, sols):
         ref = np.zeros(2 * n, bool)
-        ref[info["active"]] = True
+        ref[active] = True
         errs.append(float(np.abs(U[pos[r]] - xe).max() / max(1.0, np.abs(xe).max())))
         ham += int((bits[pos[r]] != ref).sum())
         sizes.append(int(ref.sum()))
     return {"checked": int(rows_o.size), "max_rel_err_vs_fp64_oracle": max(errs) if errs else None, "active_set_hamming": ham,
             "oracle_rows_active_set_sizes": {"min": min(sizes), "max": max(sizes)} if sizes else None,
             "largest_active_set_in_batch": int(nact.max()), "kkt_check": kkt}
+
+
+_ORACLE_JOB = None
+
+
+def _oracle_row(arg):
+    """Exact optimum and active rows of one problem of the batch (oracle.qp.solve_exact_box); runs in a forked worker."""
+    r, threads = arg
+    from oracle import qp as oqp
+    Ps, tq, nu, N, x0_h, lb_h, ub_h = _ORACLE_JOB
+
+    def run():
+        info = {"nu": nu}
+        xe = oqp.solve_exact_box(Ps, tq @ x0_h[r], np.tile(lb_h[r], N), np.tile(ub_h[r], N), info=info)
+        return xe, info["active"]
+    if threads:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=threads):
+            return run()
+    return run()
 
 
 def _row(dev, r, nbytes):
@@ -671,22 +699,30 @@ def main():
                      "batch_per_gpu": B, "total_batch": B * world, "sx": args.sx, "method": args.method,
                      "parallelism": f"dp{world} (sharded samples, 1 RCCL gather of the first moves per step, nnmpc_comm_gather_rows)"}
     if world == 1 and h is not None:
+        legs = {}
+
+        def timed(name, fn, *a):
+            t0 = time.perf_counter()
+            r = fn(*a)
+            legs[name] = round(time.perf_counter() - t0, 1)
+            return r
         if not args.no_parity:
-            out["parity"] = parity_leg(h, args.parity_rows, 2000)
-        if extras:
-            out["first_move_output"] = first_move_leg(ctx, h, args.steps)
-            if wl == "cdu":
-                out["sweep_sx"] = sweep_leg(ctx, h, [1.0, 2.0, 3.0, 4.0], 2)
-        if args.method == "auto" and not args.no_pdip:
-            out["pdip_path"] = pdip_leg(ctx, h, min(B, args.pdip_batch or (1024 if wl == "cdu" else 8192)))
+            out["parity"] = timed("parity", parity_leg, h, args.parity_rows, 2000)
+        if args.method == "auto" and not args.no_pdip:       # (compares with the headline's outputs: before they are overwritten)
+            out["pdip_path"] = timed("pdip_path", pdip_leg, ctx, h, min(B, args.pdip_batch or (1024 if wl == "cdu" else 8192)))
         if not args.no_host_io:
-            out["host_io"] = host_io_leg(ctx, h)
+            out["host_io"] = timed("host_io", host_io_leg, ctx, h)
+        if extras:
+            out["first_move_output"] = timed("first_move_output", first_move_leg, ctx, h, args.steps)
+            if wl == "cdu":
+                out["sweep_sx"] = timed("sweep_sx", sweep_leg, ctx, h, [1.0, 2.0, 3.0, 4.0], 2)
         host = h["host"]
         P, tq, nu, N = h["P"], h["tq"], h["nu"], h["N"]
         h["qp"].close(); h["buf"].free()
         if extras and wl == "cdu":
-            out["chains"] = chains_leg(ctx, "cdu", 149, 12, dict(pl=h["pl"], P=P, tq=tq, nu=nu))
+            out["chains"] = timed("chains", chains_leg, ctx, "cdu", 149, 12, dict(pl=h["pl"], P=P, tq=tq, nu=nu))
             cfg = {}
+            t_cfg = time.perf_counter()
             r2, h2 = bench_qp(ctx, "cstrs", 10000, max(args.steps, 5), 2, args.sx, want_buffers=True)
             r2["config"] = {"workload": "cstrs_offline_data: synthetic CSTRs-size plant (n=540, m=1080, cond(P) = 4e7), 10000 sampled x0, 1 GPU"}
             if not args.no_parity:
@@ -697,11 +733,13 @@ def main():
                                                   budget_s=4.0, workload="cstrs", full=False)
             h2["qp"].close(); h2["buf"].free()
             cfg["cstrs_10k"] = r2
-            cfg["nn_1m"] = bench_nn(ctx, 1 << 20, 5, 1)
+            legs["cstrs_10k"] = round(time.perf_counter() - t_cfg, 1)
+            cfg["nn_1m"] = timed("nn_1m", bench_nn, ctx, 1 << 20, 5, 1)
             out["configs"] = cfg
         if args.cpu_baseline != "none":
-            out["cpu_baseline"] = cpu_baseline(np.tril(P) + np.tril(P, -1).T, tq, nu, N, host[0][:64], host[1][:64], host[2][:64],
-                                               budget_s=20.0 if wl == "cdu" else 10.0, workload=wl, full=args.cpu_baseline == "full")
+            out["cpu_baseline"] = timed("cpu_baseline", cpu_baseline, np.tril(P) + np.tril(P, -1).T, tq, nu, N, host[0][:64], host[1][:64], host[2][:64],
+                                        12.0 if wl == "cdu" else 10.0, wl, args.cpu_baseline == "full")
+        out["leg_seconds"] = legs
     print(json.dumps(out))
 
 

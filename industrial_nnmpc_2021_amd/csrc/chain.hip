@@ -97,13 +97,80 @@ __global__ void first_moves_k(double* __restrict__ out, const double* __restrict
 
 // ---- steady-state target problems: one wave per problem.
 //   min 1/2 u'Pr u + q'u   s.t.  E u = e,  lb <= u <= ub      (nu variables, nz equalities, N = nu + nz <= 64)
-// Primal-dual active-set iterations: with the bound states fixed, ONE linear system gives (u, y):
-//   row i free:    Pr[i,:] u + E[:,i]' y = -q_i         row i at a bound:  u_i = bound_i         row nu + k:  E[k,:] u = e_k
-// solved by Gaussian elimination with partial pivoting, lane = row, matrix in LDS (stride N + 2: column N = rhs).
-// Exchange rule as in asm_update_k: every infeasible index changes sides while their number keeps reaching new minima
-// (TS_GRACE iterations of grace), then only the smallest infeasible index (Murty's rule: finite).
-constexpr int TS_GRACE = 6;
-constexpr int TS_MAXIT = 400;
+// Goldfarb-Idnani dual active-set method (strictly convex: Pr > 0): start at the optimum of the equality-constrained
+// problem, then repeatedly pick the most violated bound p and move along the direction that keeps stationarity and the
+// working set W (the equalities + the bounds held so far) while the multiplier of p grows,
+//     Pr z + E' v + sum_{i in W} s_i v_i e_i = -s_p e_p,   z_W = 0,   E z = 0          (s = +1 at an upper, -1 at a lower bound)
+// -- ONE linear system in (z_free, v) per step, Gaussian elimination with partial pivoting, lane = row, matrix in LDS --
+// until p is reached (full step: p joins W) or a multiplier of W hits zero first (that bound leaves W, same p again).
+// Finite, never visits a working set with dependent constraints (a dependent p shows as z_p = 0: pure dual step), and
+// reports infeasibility (no step possible) instead of cycling.  A final solve on the final set removes accumulated rounding
+// before the KKT conditions are checked.
+constexpr int TS_MAXIT = 600;
+
+// K [N][ld] (column N = right-hand side) -> sol [N]; returns 1 (to all lanes) when a pivot vanishes
+__device__ __forceinline__ int ts_ge_solve(double* K, int ld, int N, double* sol, int lane) {
+  double kmax = 0.0;
+  if (lane < N) for (int c = 0; c < N; ++c) kmax = fmax(kmax, fabs(K[(size_t)lane * ld + c]));
+  for (int off = 32; off > 0; off >>= 1) kmax = fmax(kmax, __shfl_xor(kmax, off));
+  __syncthreads();
+  for (int k = 0; k < N; ++k) {
+    double av = (lane >= k && lane < N) ? fabs(K[(size_t)lane * ld + k]) : -1.0;
+    int ai = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(av, off);
+      const int oi = __shfl_xor(ai, off);
+      if (ov > av || (ov == av && oi < ai)) { av = ov; ai = oi; }
+    }
+    if (!(av > 1e-13 * kmax)) return 1;                      // (wave-uniform)
+    if (ai != k) {                                           // swap rows k and ai, columns k..N
+      for (int c = k + lane; c <= N; c += 64) {
+        const double a = K[(size_t)k * ld + c], b = K[(size_t)ai * ld + c];
+        K[(size_t)k * ld + c] = b; K[(size_t)ai * ld + c] = a;
+      }
+    }
+    __syncthreads();
+    if (lane > k && lane < N) {
+      double* row = K + (size_t)lane * ld;
+      const double* pr = K + (size_t)k * ld;
+      const double f = row[k] / pr[k];
+      if (f != 0.0) for (int c = k + 1; c <= N; ++c) row[c] -= f * pr[c];
+    }
+    __syncthreads();
+  }
+  for (int k = N - 1; k >= 0; --k) {                         // back substitution, column oriented
+    if (lane == k) sol[k] = K[(size_t)k * ld + N] / K[(size_t)k * ld + k];
+    __syncthreads();
+    if (lane < k) K[(size_t)lane * ld + N] -= K[(size_t)lane * ld + k] * sol[k];
+    __syncthreads();
+  }
+  return 0;
+}
+
+// rows of the system for the current bound states: free input i: [Pr[i,:], E[:,i]'] = rf;  held input i: unit row = rh;
+// equality k: [E[k,:], 0] = re
+__device__ __forceinline__ void ts_assemble(double* K, int ld, int nu, int nz, const double* __restrict__ Pr, const double* __restrict__ E,
+                                            int lane, int st, double rf, double rh, double re) {
+  const int N = nu + nz;
+  if (lane < nu) {
+    double* row = K + (size_t)lane * ld;
+    if (st == 0) {
+      for (int c = 0; c < nu; ++c) row[c] = Pr[(size_t)lane * nu + c];
+      for (int k = 0; k < nz; ++k) row[nu + k] = E[(size_t)k * nu + lane];
+      row[N] = rf;
+    } else {
+      for (int c = 0; c < N; ++c) row[c] = c == lane ? 1.0 : 0.0;
+      row[N] = rh;
+    }
+  } else if (lane < N) {
+    double* row = K + (size_t)lane * ld;
+    const int k = lane - nu;
+    for (int c = 0; c < nu; ++c) row[c] = E[(size_t)k * nu + c];
+    for (int c = nu; c < N; ++c) row[c] = 0.0;
+    row[N] = re;
+  }
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(64) void ts_solve_k(int B, int nu, int nz, const double* __restrict__ Pr, const double* __restrict__ E,
                                                  const double* __restrict__ lbv, const double* __restrict__ ubv,
@@ -116,112 +183,110 @@ __global__ __launch_bounds__(64) void ts_solve_k(int B, int nu, int nz, const do
   const int N = nu + nz, ld = N + 2;
   double* K = sm;                                            // [N][ld]
   double* sol = K + (size_t)N * ld;                          // [N]
-  __shared__ int s_piv;
   const double* qp_ = q + (size_t)p * nu;
   const double* ep = e + (size_t)p * nz;
-  int st = 0;                                                // bound state of variable `lane` (lanes < nu)
-  int best = 0x7fffffff, grace = TS_GRACE;
-  int result = NNMPC_ST_MAXITER;
+  const bool isu = lane < nu, isy = lane >= nu && lane < N;
+  const double lbi = isu ? lbv[lane] : 0.0, ubi = isu ? ubv[lane] : 0.0;
+  const double qi = isu ? qp_[lane] : 0.0;
   // inputs a comparison cannot reason about
   int invalid = 0;
-  if (lane < nu) invalid = !(lbv[lane] <= ubv[lane]) || !(fabs(qp_[lane]) <= 1.79e308);
+  if (isu) invalid = !(lbi <= ubi) || !(fabs(qi) <= 1.79e308);
   if (lane < nz) invalid |= !(fabs(ep[lane]) <= 1.79e308);
-  if (__any(invalid)) {
-    if (lane < nu) { us[(size_t)p * nu + lane] = __longlong_as_double(0x7ff8000000000000ll); if (active) active[(size_t)p * nu + lane] = 0; }
-    if (lam_eq && lane < nz) lam_eq[(size_t)p * nz + lane] = 0.0;
-    if (lane == 0) status[p] = NNMPC_ST_NUMERIC;
-    return;
-  }
-  double uval = 0.0, yval = 0.0;
-  for (int it = 0; it < TS_MAXIT; ++it) {
-    // ---- assemble
-    if (lane < nu) {
-      double* row = K + (size_t)lane * ld;
-      if (st == 0) {
-        for (int c = 0; c < nu; ++c) row[c] = Pr[(size_t)lane * nu + c];
-        for (int k = 0; k < nz; ++k) row[nu + k] = E[(size_t)k * nu + lane];
-        row[N] = -qp_[lane];
-      } else {
-        for (int c = 0; c < N; ++c) row[c] = c == lane ? 1.0 : 0.0;
-        row[N] = st == 1 ? ubv[lane] : lbv[lane];
-      }
-    } else if (lane < N) {
-      double* row = K + (size_t)lane * ld;
-      const int k = lane - nu;
-      for (int c = 0; c < nu; ++c) row[c] = E[(size_t)k * nu + c];
-      for (int c = nu; c < N; ++c) row[c] = 0.0;
-      row[N] = ep[k];
-    }
-    double kmax = 0.0;                                       // scale of the pivot test
-    if (lane < N) for (int c = 0; c < N; ++c) kmax = fmax(kmax, fabs(K[(size_t)lane * ld + c]));
-    for (int off = 32; off > 0; off >>= 1) kmax = fmax(kmax, __shfl_xor(kmax, off));
-    __syncthreads();
-    // ---- forward elimination with partial pivoting
-    int singular = 0;
-    for (int k = 0; k < N; ++k) {
-      double av = (lane >= k && lane < N) ? fabs(K[(size_t)lane * ld + k]) : -1.0;
-      int ai = lane;
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(av, off);
-        const int oi = __shfl_xor(ai, off);
-        if (ov > av || (ov == av && oi < ai)) { av = ov; ai = oi; }
-      }
-      if (!(av > 1e-13 * kmax)) { singular = 1; break; }     // (wave-uniform) E restricted to the free inputs lost rank
-      if (ai != k) {                                         // swap rows k and ai, columns k..N
-        for (int c = k + lane; c <= N; c += 64) {
-          const double a = K[(size_t)k * ld + c], b = K[(size_t)ai * ld + c];
-          K[(size_t)k * ld + c] = b; K[(size_t)ai * ld + c] = a;
+  int result = NNMPC_ST_MAXITER;
+  int st = 0;                                                // bound state of input `lane`: 0 free, 1 at ub, 2 at lb
+  double x = 0.0, y = 0.0, mu = 0.0;                         // input value | equality multiplier | bound multiplier (>= 0)
+  if (__any(invalid)) result = NNMPC_ST_NUMERIC;
+  else {
+    // ---- optimum under the equalities alone
+    ts_assemble(K, ld, nu, nz, Pr, E, lane, 0, -qi, 0.0, isy ? ep[lane - nu] : 0.0);
+    if (ts_ge_solve(K, ld, N, sol, lane)) result = NNMPC_ST_NUMERIC;     // E itself is rank deficient
+    else {
+      x = isu ? sol[lane] : 0.0;
+      y = isy ? sol[lane] : 0.0;
+      int it = 0;
+      bool done = false;
+      while (!done && it < TS_MAXIT) {
+        // ---- most violated bound among the free inputs (ties: smallest index)
+        double viol = (isu && st == 0) ? fmax(x - ubi, lbi - x) : -1e300;
+        int pi = lane;
+        for (int off = 32; off > 0; off >>= 1) {
+          const double ov = __shfl_xor(viol, off);
+          const int oi = __shfl_xor(pi, off);
+          if (ov > viol || (ov == viol && oi < pi)) { viol = ov; pi = oi; }
+        }
+        if (!(viol > bound_tol)) { result = NNMPC_ST_OPTIMAL; break; }
+        const double xp = __shfl(x, pi), ubp = __shfl(ubi, pi), lbp = __shfl(lbi, pi);   // (x of pi moves in the steps below)
+        const double sp = xp > ubp ? 1.0 : -1.0, bp = xp > ubp ? ubp : lbp;
+        // ---- steps towards bound pi
+        for (;; ++it) {
+          if (it >= TS_MAXIT) { done = true; break; }
+          ts_assemble(K, ld, nu, nz, Pr, E, lane, st, lane == pi ? -sp : 0.0, 0.0, 0.0);
+          if (ts_ge_solve(K, ld, N, sol, lane)) { result = NNMPC_ST_NUMERIC; done = true; break; }
+          const double z = isu ? sol[lane] : 0.0, v = isy ? sol[lane] : 0.0;
+          double vi = 0.0;                                   // rate of this input's bound multiplier
+          if (isu && st != 0) {
+            double g = 0.0;
+            for (int c = 0; c < nu; ++c) g += Pr[(size_t)lane * nu + c] * sol[c];
+            for (int k = 0; k < nz; ++k) g += E[(size_t)k * nu + lane] * sol[nu + k];
+            vi = st == 1 ? -g : g;
+          }
+          const double zp = __shfl(z, pi), xpc = __shfl(x, pi);
+          // a bound that depends on the working set shows as z = 0 (up to rounding; an independent one moves its input by
+          // the order of 1 / Pr_pp per unit multiplier): no primal step possible then, only multipliers move
+          const double t2 = (fabs(zp) * Pr[(size_t)pi * nu + pi] > 1e-9 && (bp - xpc) / zp > 0.0) ? (bp - xpc) / zp : 1e300;
+          double t1 = (isu && st != 0 && vi < -1e-14) ? mu / -vi : 1e300;
+          int kb = lane;
+          for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(t1, off);
+            const int oi = __shfl_xor(kb, off);
+            if (ov < t1 || (ov == t1 && oi < kb)) { t1 = ov; kb = oi; }
+          }
+          const double t = fmin(t1, t2);
+          if (!(t < 1e299)) { result = NNMPC_ST_NUMERIC; done = true; break; }    // no steady state inside the input box
+          if (isu) { if (st == 0) x += t * z; else mu += t * vi; }
+          if (isy) y += t * v;
+          if (lane == pi) mu += t;
+          if (t2 <= t1) {                                    // full step: the bound joins the working set
+            if (lane == pi) { st = sp > 0.0 ? 1 : 2; x = bp; }
+            ++it;
+            break;
+          }
+          if (lane == kb) { st = 0; mu = 0.0; }              // its multiplier reached zero: the bound leaves, same p again
         }
       }
-      __syncthreads();
-      if (lane > k && lane < N) {
-        double* row = K + (size_t)lane * ld;
-        const double* pr = K + (size_t)k * ld;
-        const double f = row[k] / pr[k];
-        if (f != 0.0) for (int c = k + 1; c <= N; ++c) row[c] -= f * pr[c];
+      if (result == NNMPC_ST_OPTIMAL) {
+        // ---- final solve on the final set, then the KKT conditions in full
+        ts_assemble(K, ld, nu, nz, Pr, E, lane, st, -qi, st == 1 ? ubi : lbi, isy ? ep[lane - nu] : 0.0);
+        if (ts_ge_solve(K, ld, N, sol, lane)) result = NNMPC_ST_NUMERIC;
+        else {
+          x = isu ? sol[lane] : 0.0;
+          y = isy ? sol[lane] : 0.0;
+          int bad = 0;
+          double scale = 1.0;
+          if (isu) {
+            double g = qi;
+            for (int c = 0; c < nu; ++c) g += Pr[(size_t)lane * nu + c] * sol[c];
+            for (int k = 0; k < nz; ++k) g += E[(size_t)k * nu + lane] * sol[nu + k];
+            scale = fmax(1.0, fabs(qi));
+            if (st == 0) bad = !(fabs(g) <= 1e-8 * scale) || !(x <= ubi + bound_tol) || !(x >= lbi - bound_tol);
+            else bad = st == 1 ? !(g <= 1e-9 * scale) : !(g >= -1e-9 * scale);     // multiplier -s g >= 0 (zero: weakly active)
+            if (st == 1) x = ubi; else if (st == 2) x = lbi;
+          }
+          if (isy) {
+            double r = -ep[lane - nu];
+            for (int c = 0; c < nu; ++c) r += E[(size_t)(lane - nu) * nu + c] * sol[c];
+            bad = !(fabs(r) <= 1e-9 * fmax(1.0, fabs(ep[lane - nu])));
+          }
+          if (__any(bad)) result = NNMPC_ST_MAXITER;
+        }
       }
-      __syncthreads();
     }
-    if (singular) { result = NNMPC_ST_NUMERIC; break; }
-    // ---- back substitution (column oriented)
-    for (int k = N - 1; k >= 0; --k) {
-      if (lane == k) { const double v = K[(size_t)k * ld + N] / K[(size_t)k * ld + k]; sol[k] = v; }
-      __syncthreads();
-      if (lane < k) K[(size_t)lane * ld + N] -= K[(size_t)lane * ld + k] * sol[k];
-      __syncthreads();
-    }
-    uval = lane < nu ? sol[lane] : 0.0;
-    yval = (lane >= nu && lane < N) ? sol[lane] : 0.0;
-    // ---- KKT tests: g = Pr u + q + E'y
-    int inf = 0, ns = st;
-    if (lane < nu) {
-      double g = qp_[lane];
-      for (int c = 0; c < nu; ++c) g += Pr[(size_t)lane * nu + c] * sol[c];
-      for (int k = 0; k < nz; ++k) g += E[(size_t)k * nu + lane] * sol[nu + k];
-      if (st == 0) {
-        if (!(uval <= ubv[lane] + bound_tol)) { inf = 1; ns = 1; }
-        else if (!(uval >= lbv[lane] - bound_tol)) { inf = 1; ns = 2; }
-      } else if (st == 1) { if (!(g < 0.0)) { inf = 1; ns = 0; } }
-      else { if (!(g > 0.0)) { inf = 1; ns = 0; } }
-    }
-    const unsigned long long mk = __ballot(inf);
-    const int ninf = __popcll(mk);
-    if (ninf == 0) { result = NNMPC_ST_OPTIMAL; break; }
-    int single = 0;
-    if (ninf < best) { best = ninf; grace = TS_GRACE; }
-    else if (grace > 0) --grace;
-    else single = 1;
-    const int first = __ffsll((long long)mk) - 1;
-    if (!single || lane == first) st = ns;
-    __syncthreads();
   }
-  if (lane < nu) {
-    double v = uval;
-    if (result == NNMPC_ST_OPTIMAL && st) v = st == 1 ? ubv[lane] : lbv[lane];
-    us[(size_t)p * nu + lane] = v;
-    if (active) active[(size_t)p * nu + lane] = (unsigned char)st;
+  if (isu) {
+    us[(size_t)p * nu + lane] = result == NNMPC_ST_NUMERIC ? __longlong_as_double(0x7ff8000000000000ll) : x;
+    if (active) active[(size_t)p * nu + lane] = result == NNMPC_ST_NUMERIC ? 0 : (unsigned char)st;
   }
-  if (lam_eq && lane >= nu && lane < N) lam_eq[(size_t)p * nz + lane - nu] = yval;
+  if (lam_eq && isy) lam_eq[(size_t)p * nz + lane - nu] = y;
   if (lane == 0) status[p] = result;
 }
 

@@ -37,7 +37,11 @@ constexpr int ASM_NBIN = 8;        // size classes by the number of 16-blocks: c
 constexpr int ASM_NREG = 6;        // classes 0..5 (<= 144 bounds): four problems per workgroup (asm_lambda_reg_k); 6, 7: two
 constexpr int ASM_NCNT = 40;       // ints in AsmDev::counters
 constexpr int ASM_CNT_F32 = 16;    // counters[16 + b]: length of the f32 list of size class b
-constexpr int ASM_NLIST = 2 * ASM_NBIN;   // lists in AsmDev::binlist: fp64 classes, then f32 classes
+constexpr int ASM_NLIST = 2 * ASM_NBIN;   // lists in AsmDev::binlist: fp64 classes, then f32 classes, then (list ASM_NLIST) the
+                                          // f32 rounds of sets of ASM_MLDS + 1 .. ASM_BIG32 bounds (asm_lambda_tile32_k)
+constexpr int ASM_BIG32 = 256;            // largest set whose f32 rounds run with the tiles in LDS (16 x 16 lower f32 tiles, one
+                                          // workgroup per problem); beyond: fp64 from the start, tiles in an L2 slab
+constexpr int ASM_CNT_BIG32 = 36;         // counters[36]: length of list ASM_NLIST
 constexpr int ASM_GRACE = 10;       // rounds without a new minimum of infeasible indices before single exchanges take over
 constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last asm_wide_k (statistics)
 constexpr int ASM_CNT_WIDEG = 24;  // counters[24 + g]: problems of k-group g awaiting the full-width check (their rows of
@@ -49,10 +53,12 @@ constexpr int ASM_CNT_WDONE = 32;  // counters[32 + g]: problems of group g hand
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
 // ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
-__host__ __device__ constexpr int asm_list_counter(int list) { return list < ASM_NBIN ? 4 + list : ASM_CNT_F32 + list - ASM_NBIN; }
+__host__ __device__ constexpr int asm_list_counter(int list) {
+  return list < ASM_NBIN ? 4 + list : (list < ASM_NLIST ? ASM_CNT_F32 + list - ASM_NBIN : ASM_CNT_BIG32);
+}
 constexpr int ASM_NKG = 3;         // rows of a round are ordered by the last active stage (groups: <= median, +1, beyond),
                                    // so that a 128-row block of the GEMM stops its k-loop at ITS last active bound
-constexpr int ASM_NSCAN = ASM_NLIST + 3 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, sum and max of
+constexpr int ASM_NSCAN = ASM_NLIST + 4 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, sum and max of
                                                         // the last active indices
 constexpr int ASM_CNT_ROWS32 = 15; // counters[15]: rows of LAM32 / XH32 handed out ([2]: rows of LAM / XH)
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
       const double md = (double)m;
       d.work[3 * p] += md * md * md / 3.0 + 2.0 * md * md;             // per-problem slots: same-address atomics
       d.work[3 * p + 1] += 8.0 * (md * (md + 1.0) / 2.0 + 2.0 * md);   // (one per workgroup) serialise the launch
-      if (d.prec[p] == 0 && m <= ASM_MLDS) d.work[3 * p + 2] += md * md * md / 3.0 + 2.0 * md * md;   // ... of which in an f32 round
+      if (d.prec[p] == 0 && m <= ASM_BIG32) d.work[3 * p + 2] += md * md * md / 3.0 + 2.0 * md * md;   // ... of which in an f32 round
     }
     if (m > d.max_active) d.state[p] = ASM_FALLBACK;
   }
@@ -232,12 +238,12 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // the round) is reset here.
 // scan columns: 0 large sets, 1 + list, ASM_COL_ROW + prec * ASM_NKG + group (rows of LAM / LAM32), then the sum of
 // (last active index + 1) and the max index
-constexpr int ASM_COL_ROW = 1 + ASM_NLIST;
+constexpr int ASM_COL_ROW = 2 + ASM_NLIST;
 __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + list otherwise
   run = p < d.nseg && d.state[p] == ASM_RUN;
   if (!run) return -1;
   const int m = d.mg[p];
-  if (m > ASM_MLDS) return 0;
+  if (m > ASM_MLDS) return (d.prec[p] == 0 && m <= ASM_BIG32) ? 1 + ASM_NLIST : 0;
   const int b = max((m + 15) / 16, 4) - 4;
   return 1 + (d.prec[p] == 0 ? ASM_NBIN + b : b);
 }
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
     if (lane == 0) wtot[ASM_COL_ROW + c][wave] = __popcll(mk);
   }
 #pragma unroll
-  for (int c = 0; c <= ASM_NLIST; ++c) {
+  for (int c = 0; c <= ASM_NLIST + 1; ++c) {
     const unsigned long long mk = __ballot(col == c);
     if (col == c) myrank = __popcll(mk & lt);
     if (lane == 0) wtot[c][wave] = __popcll(mk);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
       d.counters[ASM_CNT_WIDE + 1] = nw;
     } else if (tid == ASM_NSCAN - 2) d.counters[0] = total[tid];   // sum of (last active index + 1): algorithmic k of the GEMM
     else if (tid == 0) d.counters[1] = total[0];
-    else if (tid <= ASM_NLIST) d.counters[asm_list_counter(tid - 1)] = total[tid];
+    else if (tid <= ASM_NLIST + 1) d.counters[asm_list_counter(tid - 1)] = total[tid];
     else if (tid == ASM_COL_ROW) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + g]; d.counters[2] = t; }
     else if (tid == ASM_COL_ROW + ASM_NKG) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + ASM_NKG + g]; d.counters[ASM_CNT_ROWS32] = t; }
   }
@@ -489,7 +495,7 @@ __device__ __forceinline__ int asm_tile_solve(const AsmDev& d, int p, int m, con
 }
 
 template <int BIG>
-__global__ __launch_bounds__(256, 2) void asm_lambda_tile_k(AsmDev d, int bin) {
+__global__ __launch_bounds__(256, 4) void asm_lambda_tile_k(AsmDev d, int bin) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_bad;
   const int tid = threadIdx.x;
@@ -825,6 +831,162 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
   for (int I = 0; I < MB; ++I) {
     const int i = 16 * I + li;
     if (lq == 0 && i < m) lrow[idx[i]] = (LT)lam[I];
+  }
+}
+
+// ---- f32 rounds of the sets beyond the register kernels (ASM_MLDS + 1 .. ASM_BIG32 bounds): the same blocked Cholesky as
+// asm_tile_solve, one workgroup (eight waves) per problem, in f32 with ALL tiles in LDS (136 tiles of 16 x 17 floats at 256
+// bounds: 148 KB) -- the eight waves share the TRSM and trailing MFMAs (v_mfma_f32_16x16x4_f32) of a block column.  As in the
+// register kernels an f32 result only moves the set; a set that settles is solved again in fp64 (asm_lambda_tile_k<1>).
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v_t tile_mma_nt32(const float* A, const float* B, int lane) {
+  f32x4v_t acc = {0.f, 0.f, 0.f, 0.f};
+  const int li = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[li * 17 + 4 * s + kq], B[li * 17 + 4 * s + kq], acc, 0, 0, 0);
+  return acc;                                            // reg r of lane (li, lq): row 4 lq + r, column li
+}
+__device__ __forceinline__ float* asm_tile32(float* T, int I, int J) { return T + ((size_t)I * (I + 1) / 2 + J) * ASM_TS; }
+template <class T> __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane);
+
+// rA [>= 16 ceil(m/16)], Yt [ASM_TS], T [tiles] in LDS; returns 1 (to all threads) when H_AA is not positive definite in f32
+__device__ __forceinline__ int asm_tile_solve32(const AsmDev& d, int p, int m, const int* idx, float* rA, float* Yt, float* T, int* s_bad) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+  if (tid == 0) *s_bad = 0;
+  const size_t o = (size_t)p * d.np;
+  const unsigned char* st = d.st + (size_t)p * d.n;
+  const int mb = (m + 15) / 16;
+  __syncthreads();
+  for (int i = tid; i < mb * 16; i += 512) {
+    float v = 0.f;
+    if (i < m) {
+      const int a = idx[i], k = a % d.nu;
+      v = (float)(d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]));
+    }
+    rA[i] = v;
+  }
+  const int ntile = mb * (mb + 1) / 2;
+  {
+    // thread (half, ti, tj) fetches element (ti, tj) of every second tile, 8 at a time: 8 gathers in flight per thread
+    // (the entries come from L2 / Infinity Cache, ~1 us each: the gather is a latency chain, not a bandwidth one)
+    const int half = tid >> 8, ti = (tid >> 4) & 15, tj = tid & 15;
+    for (int t0 = half; t0 < ntile; t0 += 2 * 8) {
+      float v[8];
+      int tt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + 2 * u;
+        // tile t -> (I, J): I = largest with I (I + 1) / 2 <= t
+        int I = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        while (I * (I + 1) / 2 > t) --I;
+        const int J = t - I * (I + 1) / 2;
+        tt[u] = t;
+        const int gi = 16 * I + ti, gj = 16 * J + tj;
+        v[u] = gi == gj ? 1.f : 0.f;
+        if (t < ntile && gi < m && gj < m) v[u] = d.H32[(size_t)idx[gi] * d.np + idx[gj]];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (tt[u] < ntile) (T + (size_t)tt[u] * ASM_TS)[ti * 17 + tj] = v[u];
+    }
+  }
+  __syncthreads();
+  for (int K = 0; K < mb; ++K) {
+    float* TKK = asm_tile32(T, K, K);
+    if (wave == 0) {
+      const int bad = asm_diag16<float>(TKK, Yt, lane);
+      if (bad && lane == 0) *s_bad = 1;
+    }
+    __syncthreads();
+    for (int I = K + 1 + wave; I < mb; I += 8) {         // TRSM: T(I,K) <- T(I,K) Y'   (eight waves)
+      float* TIK = asm_tile32(T, I, K);
+      const f32x4v_t acc = tile_mma_nt32(TIK, Yt, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) TIK[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[r];
+    }
+    __syncthreads();
+    {
+      int b = 0;
+      for (int I = K + 1; I < mb; ++I)
+        for (int J = K + 1; J <= I; ++J, ++b) {
+          if ((b & 7) != wave) continue;
+          const f32x4v_t acc = tile_mma_nt32(asm_tile32(T, I, K), asm_tile32(T, J, K), lane);
+          float* TIJ = asm_tile32(T, I, J);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) TIJ[(4 * (lane >> 4) + r) * 17 + (lane & 15)] -= acc[r];
+        }
+    }
+    if (wave == 0 && lane < 16) {                          // Y_K' into the upper part of T(K,K) for the solves
+      const int row = lane;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) if (k >= row) TKK[row * 17 + k] = Yt[k * 17 + row];
+    }
+    __syncthreads();
+  }
+  if (*s_bad) return 1;
+  if (wave == 0) {
+    const int i = lane & 15, kq = lane >> 4;
+    for (int K = 0; K < mb; ++K) {                       // forward
+      float t = 0.f;
+      for (int J = 0; J < K; ++J) {
+        const float* TKJ = asm_tile32(T, K, J);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += TKJ[i * 17 + 4 * kq + k] * rA[16 * J + 4 * kq + k];
+      }
+      t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+      t = rA[16 * K + i] - t;
+      const float* TKK = asm_tile32(T, K, K);
+      float yv = t * TKK[i * 17 + i];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float tk = __shfl(t, k); if (k < i) yv += TKK[k * 17 + i] * tk; }
+      if (lane < 16) rA[16 * K + i] = yv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int K = mb - 1; K >= 0; --K) {                  // backward
+      float t = 0.f;
+      for (int I = K + 1; I < mb; ++I) {
+        const float* TIK = asm_tile32(T, I, K);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += TIK[(4 * kq + k) * 17 + i] * rA[16 * I + 4 * kq + k];
+      }
+      t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+      t = rA[16 * K + i] - t;
+      const float* TKK = asm_tile32(T, K, K);
+      float lv = t * TKK[i * 17 + i];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float tk = __shfl(t, k); if (k > i) lv += TKK[i * 17 + k] * tk; }
+      if (lane < 16) rA[16 * K + i] = lv;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  return 0;
+}
+
+constexpr int ASM_TILE32_LDS = (ASM_BIG32 + ASM_TS + (ASM_BIG32 / 16) * (ASM_BIG32 / 16 + 1) / 2 * ASM_TS) * 4;
+__global__ __launch_bounds__(512, 1) void asm_lambda_tile32_k(AsmDev d) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  float* rA = smf;                                       // [ASM_BIG32]
+  float* Yt = rA + ASM_BIG32;
+  float* T = Yt + ASM_TS;
+  const int nitem = d.counters[ASM_CNT_BIG32];
+  const int* list = d.binlist + (size_t)ASM_NLIST * d.nseg;
+  for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
+    const int p = list[it];
+    const int* idx = d.idxg + (size_t)p * d.max_active;
+    const int m = d.mg[p];
+    if (asm_tile_solve32(d, p, m, idx, rA, Yt, T, &s_bad)) {
+      // not positive definite in f32: the round is void (the LAM32 row is still zero), the next one runs in fp64
+      if (tid == 0) { d.prec[p] = 1; d.redo[p] = 1; }
+      continue;
+    }
+    float* lrow = d.lam32 + (size_t)d.row[p] * d.np;
+    for (int i = tid; i < m; i += 512) lrow[idx[i]] = rA[i];
   }
 }
 

@@ -976,6 +976,17 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         h->stats.asm_gemm_flops += 2.0 * wide_cols * ksum;
     }
     kprev = cnt[3];
+    {
+      static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: the populations of every round
+      if (trace) {
+        fprintf(stderr, "asm round %d: fp64 %d f32 %d last-active %d wide-checked %d big %d big32 %d | fp64 classes", rounds, n64, n32, cnt[3],
+                cnt[ASM_CNT_WIDE + 1], cnt[1], cnt[ASM_CNT_BIG32]);
+        for (int b = 0; b < ASM_NBIN; ++b) fprintf(stderr, " %d", cnt[4 + b]);
+        fprintf(stderr, " | f32 classes");
+        for (int b = 0; b < ASM_NBIN; ++b) fprintf(stderr, " %d", cnt[ASM_CNT_F32 + b]);
+        fprintf(stderr, "\n");
+      }
+    }
     if (nrun == 0) break;
     if (nrun <= std::min(h->asm_pool, 256) && rounds >= 6) {
       // the tail: a handful of stragglers (the bulk settles in 5-8 rounds) -- finish them on the device (asm_tail_k)
@@ -1002,13 +1013,14 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // workgroup each: long latency chains on a handful of CUs) beside it on the side stream.
       const int nreg2_wg = (cnt[4 + 6] + 1) / 2 + (cnt[4 + 7] + 1) / 2;
       const int nreg32b_wg = (cnt[ASM_CNT_F32 + 6] + 3) / 4 + (cnt[ASM_CNT_F32 + 7] + 3) / 4;
-      int nbig = cnt[1] + nreg2_wg + nreg32b_wg, nreg_wg = 0, nreg32_wg = 0;
+      int nbig = cnt[1] + cnt[ASM_CNT_BIG32] + nreg2_wg + nreg32b_wg, nreg_wg = 0, nreg32_wg = 0;
       for (int b = 0; b < ASM_NREG; ++b) { nreg_wg += (cnt[4 + b] + 3) / 4; nreg32_wg += (cnt[ASM_CNT_F32 + b] + 3) / 4; }
       if (nbig) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         if (nreg2_wg) hipLaunchKernelGGL(asm_lambda_reg2_k, dim3(nreg2_wg), dim3(128), ASM_REG2_LDS, h->stream2, a);
         if (nreg32b_wg) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3(nreg32b_wg), dim3(256), ASM_REG32B_LDS, h->stream2, a);
+        if (cnt[ASM_CNT_BIG32]) hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(cnt[ASM_CNT_BIG32], 4096)), dim3(512), ASM_TILE32_LDS, h->stream2, a);
         if (cnt[1]) hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream2, a, 0);
         HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       }
@@ -1168,6 +1180,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32b_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32B_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_tile32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_TILE32_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_kdyn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
@@ -1210,12 +1223,14 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->in_stage, G * n_aug);
   A_(d.lb64, (size_t)S * nu); A_(d.ub64, (size_t)S * nu);
   A_(d.slot_prob, S); A_(d.age, S); A_(d.next_prob, 1);
-  h->asm_pool = 256;
+  // workgroups of the large-set kernel in flight (each with its tile slab in HBM / L2): four per CU for bulk batches --
+  // the kernel is a latency chain (barriers, tiles in global memory), occupancy is what hides it
+  h->asm_pool = h->seg_max >= 4096 ? 1024 : 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka); A_(h->H32, (size_t)np * np);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
-  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)ASM_NLIST * G);
+  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 1) * G);
   A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 3 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_

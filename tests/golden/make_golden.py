@@ -44,6 +44,9 @@ def import_reference():
             x = oqp.solve_exact(P, q, G, h)
         else:
             x = oqp.solve_exact_eq(P, q, G, h, A, b)
+            # a fixture must not contain an infeasible target problem (cvxopt would return status 'unknown' there)
+            if np.abs(np.asarray(A) @ x - np.asarray(b).ravel()).max() > 1e-8 or (np.asarray(G) @ x - np.asarray(h).ravel()).max() > 1e-8:
+                raise ArithmeticError("make_golden: infeasible equality-constrained QP in a fixture run")
         return {"x": np.asarray(x).reshape(-1, 1), "status": "optimal"}
 
     cvx.solvers = types.SimpleNamespace(qp=qp, options={})
@@ -99,7 +102,7 @@ def make_target(ref):
         ysp = rng.uniform(0.3, 1.2) * rng.standard_normal((Ny, 1)); d = rng.standard_normal((Nd, 1))
         try:
             xs, us = ts.solve(ysp, d)
-        except np.linalg.LinAlgError:
+        except (np.linalg.LinAlgError, ArithmeticError):
             continue                                          # no steady state inside the input box
         (q, h, b) = ts._setup_changing_matrices(ysp, d)
         z0 = np.concatenate((xs, us)).ravel()
@@ -132,8 +135,8 @@ def make_closed_loop(ref, ce):
     Rs, Qs = 1e-3 * np.eye(Nu), np.eye(Ny)
     Qwx, Qwd, Rv = 1e-4 * np.eye(Nx), 1e-2 * np.eye(Nd), 1e-4 * np.eye(Ny)
     ulb, uub = -np.ones((Nu, 1)), np.ones((Nu, 1))
-    setpoints = np.repeat(rng.uniform(-1.5, 1.5, (3, Ny)), Nsim // 3 + 1, axis=0)[:Nsim]
-    disturbances = np.repeat(rng.uniform(-1, 1, (2, Nd)), Nsim // 2 + 1, axis=0)[:Nsim]
+    setpoints = np.repeat(rng.uniform(-0.4, 0.4, (3, Ny)), Nsim // 3 + 1, axis=0)[:Nsim]      # reachable inside the input box
+    disturbances = np.repeat(rng.uniform(-0.5, 0.5, (2, Nd)), Nsim // 2 + 1, axis=0)[:Nsim]
     common = dict(A=A, B=B, C=C, H=H, Qwx=Qwx, Qwd=Qwd, Rv=Rv, xprior=np.zeros((Nx, 1)), dprior=np.zeros((Nd, 1)),
                   Rs=Rs, Qs=Qs, Bd=Bd, Cd=Cd, usp=np.zeros((Nu, 1)), uprev=np.zeros((Nu, 1)), Q=Q, R=R, S=S, ulb=ulb, uub=uub)
     # NN weights: small, so that the loop stays the plant's own stable dynamics plus a bounded input

@@ -36,3 +36,35 @@ def oracle_solve(reg, x0, lb, ub):
         act[b, info["active"]] = True
         assert info["kkt"][0] < 1e-6 * max(1.0, np.abs(reg.tq @ x0[b]).max()) and info["kkt"][1] < 1e-9
     return U, act
+
+
+_JOB = None
+
+
+def _oracle_box_row(arg):
+    r, threads = arg
+    Ps, tq, nu, N, x0, lb, ub = _JOB
+
+    def run():
+        info = {"nu": nu}
+        xe = oqp.solve_exact_box(Ps, tq @ x0[r], np.tile(lb[r], N), np.tile(ub[r], N), info=info)
+        return xe, info["active"]
+    if threads:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=threads):
+            return run()
+    return run()
+
+
+def oracle_box_rows(Ps, tq, nu, N, x0, lb, ub, rows):
+    """[(u*, active rows of G)] of the listed problems by oracle.qp.solve_exact_box, in forked workers (the solves are
+    independent and take seconds each at the CDU size; the workers inherit the matrices and never touch the GPU)."""
+    import multiprocessing as mp
+    import os
+    global _JOB
+    _JOB = (Ps, tq, nu, N, x0, lb, ub)
+    nw = max(1, min(16, len(rows), (os.cpu_count() or 1) // 4))
+    if nw == 1 or Ps.shape[0] < 1024:
+        return [_oracle_box_row((int(r), 0)) for r in rows]
+    with mp.get_context("fork").Pool(nw) as pool:
+        return pool.map(_oracle_box_row, [(int(r), max(1, (os.cpu_count() or 1) // (2 * nw))) for r in rows])

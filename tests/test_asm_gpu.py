@@ -1,7 +1,7 @@
 """GPU parity tests of the active-set fast path (qp_asm.h) on generic box QPs, through the C ABI.
 
 Every size class of the multiplier-system kernels (register-resident 4..9 blocks, LDS tiles 10..11
-blocks, the L2-slab kernel beyond) and the column-window / full-width re-entry logic get their own
+blocks, the f32 LDS-tile workgroup kernel up to 16 blocks, the L2-slab kernel beyond) and the column-window / full-width re-entry logic get their own
 cases; the oracle is the fp64 interior-point + active-set restatement in oracle/qp.py.
 """
 import numpy as np
@@ -35,7 +35,7 @@ def _qp(P, nu, **kw):
 
 
 @pytest.mark.parametrize("f32_rounds", [0, -1])       # 0: rounds in f32 until the set settles, then fp64; -1: fp64 throughout
-@pytest.mark.parametrize("n_active_target", [20, 60, 72, 85, 98, 110, 122, 135, 145, 230])
+@pytest.mark.parametrize("n_active_target", [20, 60, 72, 85, 98, 110, 122, 135, 145, 165, 200, 230])
 def test_size_classes(n_active_target, f32_rounds):
     """Sets of ~20 .. ~280 bounds (the couplings add ~20 % to the pushed ones): every kernel variant must
     reproduce the exact optimum and set."""

@@ -70,11 +70,10 @@ def _check(P, tq, nu, N, x0, lb, ub, u_dev, act, rows_kkt, rows_oracle):
     assert (np.abs(np.where(~(au | al), G, 0)) <= 1e-7 * scale).all()
     assert (np.where(au, -G, 1) > 0).all() and (np.where(al, G, 1) > 0).all()
     pos = {int(r): i for i, r in enumerate(rows)}
-    for r in rows_oracle:
-        info = {"nu": nu}
-        xe = oqp.solve_exact_box(Ps, tq @ x0[r], np.tile(lb[r], N), np.tile(ub[r], N), info=info)
+    from tests.helpers import oracle_box_rows
+    for r, (xe, active) in zip(rows_oracle, oracle_box_rows(Ps, tq, nu, N, x0, lb, ub, rows_oracle)):
         ref = np.zeros(2 * n, bool)
-        ref[info["active"]] = True
+        ref[active] = True
         i = pos[int(r)]
         assert np.abs(U[i] - xe).max() <= 1e-8 * max(1.0, np.abs(xe).max()), r
         assert np.array_equal(bits[i], ref), (r, int((bits[i] != ref).sum()))
