@@ -116,6 +116,7 @@ struct AsmDev {
   const double* xhw;               // [rows] = lamw * H, all columns
   int* wlist;                      // [ASM_NKG][wcap] those problems by k-group; their numbers are counters[ASM_CNT_WIDEG + g]
   int wcap;                        // rows per region of lamw / xhw / wlist
+  int* wflag;                      // [nseg] set by asm_wide_gemm_k when a bound beyond the window is violated (cleared by asm_wide_k)
   double* work;                    // [nseg][3] statistics: flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels, flops of the f32 rounds
   double* scratch;                 // [pool][tiles(max_active) * ASM_TS] tile slabs of the queue kernel
   // outputs (problem-indexed, may be null except u)
@@ -1180,7 +1181,11 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
 // Full-width check of the problems that settled inside the window (xhw = lamw * H over all columns):
 // a bound violated beyond the window joins the set and the problem runs on; otherwise it is finished
 // exactly like in asm_update_k.  Runs at the start of a round, before asm_count_k.
-__global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
+__global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
+  // fused_c0 >= 0: the columns [fused_c0, n) were checked and written by asm_wide_gemm_k (qp_wide.h), which raised
+  // wflag[p] for a violated bound; this kernel does the columns inside the window, the multiplier statistics and the
+  // decision.  fused_c0 < 0: everything from the XHW rows of a plain GEMM (shapes the fused kernel's tiles do not fit).
+  extern __shared__ double wl_lam[];                         // [max_active] multipliers (rare path: x again, from Pinv)
   __shared__ int cnt[4];
   __shared__ double red[12];
   const int g = blockIdx.y, tid = threadIdx.x;
@@ -1189,13 +1194,24 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
   const int p = d.wlist[w];
   const size_t o = (size_t)p * d.np, orow = (size_t)w * d.np;
   // columns inside the window the problem settled in (d.W is still that round's) were evaluated by that round's
-  // GEMM: its row of XH is untouched until this round's GEMM; only the columns beyond come from XHW
+  // GEMM: its row of XH is untouched until this round's GEMM; only the columns beyond come from the wide pass
   const size_t onar = (size_t)d.row[p] * d.np;
   const int Wp = min(d.W, d.n);
+  const bool fused = fused_c0 >= 0;
+  const int rend = fused ? min(fused_c0, d.n) : d.n;         // columns this kernel evaluates
   unsigned char* st = d.st + (size_t)p * d.n;
+  const int m = d.mg[p];                                     // the settled set: idx[0..m) (unchanged since asm_count_k)
+  const int* idx = d.idxg + (size_t)p * d.max_active;
   int chg = 0;
   double l1 = 0.0, lmin = 1e300;
-  for (int r = tid; r < d.n; r += 256) {
+  for (int i = tid; i < m; i += 256) {                       // multipliers of the settled set; the LAMW row goes back to zero
+    const int a = idx[i];
+    const double l = d.lamw[orow + a];
+    d.lamw[orow + a] = 0.0;
+    wl_lam[i] = l;
+    l1 += fabs(l); lmin = fmin(lmin, fabs(l));
+  }
+  for (int r = tid; r < rend; r += 256) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     const int s = st[r];
@@ -1204,14 +1220,10 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
       x = d.xunc[o + r] - (r < Wp ? d.xh[onar + r] : d.xhw[orow + r]);
       if (x > ub + d.bound_tol) { st[r] = 1; ++chg; }
       else if (x < lb - d.bound_tol) { st[r] = 2; ++chg; }
-    } else {
-      const double l = d.lamw[orow + r];
-      d.lamw[orow + r] = 0.0;
-      l1 += fabs(l); lmin = fmin(lmin, fabs(l));
-      x = s == 1 ? ub : lb;
-    }
+    } else x = s == 1 ? ub : lb;
     if (r < d.nout) d.u_out[(size_t)p * d.ldu + r] = x;      // final if nothing changes
   }
+  if (fused && tid == 0) { chg += d.wflag[p]; d.wflag[p] = 0; }
   double x1 = 0.0;
   for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
   for (int off = 32; off > 0; off >>= 1) {
@@ -1233,8 +1245,17 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d) {
   if (tot == 0 && !sure) {                                   // P itself has to confirm this one: x as a GEMM row
     for (int r = tid; r < d.n; r += 256) {                   // (nothing changed: st still is the set x belongs to)
       const int k = r % d.nu, s = st[r];
-      d.x[o + r] = s == 0 ? d.xunc[o + r] - (r < Wp ? d.xh[onar + r] : d.xhw[orow + r])
-                          : (s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+      double x;
+      if (s != 0) x = s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k];
+      else if (r < Wp) x = d.xunc[o + r] - d.xh[onar + r];
+      else if (!fused) x = d.xunc[o + r] - d.xhw[orow + r];
+      else {                                                 // rare: the product again, straight from Pinv (as asm_tail_k does)
+        const double* Hc = d.H + r;
+        double a0 = 0.0;
+        for (int i = 0; i < m; ++i) a0 += Hc[(size_t)idx[i] * d.np] * wl_lam[i];
+        x = d.xunc[o + r] - a0;
+      }
+      d.x[o + r] = x;
     }
   }
   if (tid == 0) {

@@ -28,6 +28,7 @@
 #include "chol_kernels.h"
 #include "gemm_kernels.h"
 #include "qp_asm.h"
+#include "qp_wide.h"
 #include "common.h"
 
 using namespace nnmpc;
@@ -663,7 +664,7 @@ struct nnmpc_qp {
   double* H64;      // np x np
   double* Kunc64;   // np x ka
   double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch, *asm_lamw, *asm_xhw;
-  int* asm_wlist;
+  int *asm_wlist, *asm_wflag;
   unsigned char* asm_st;
   int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row, *asm_lrank, *asm_ctot;
   unsigned char *asm_prec, *asm_redo, *asm_alpha, *asm_rowk;
@@ -927,7 +928,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wflag = h->asm_wflag; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.ldu = h->ldu; a.nout = h->nout; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
@@ -937,7 +938,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   int cnt[ASM_NCNT] = {0};
   int rounds = 0;
   int prev_run = 0;                                     // upper bound of the problems awaiting the full-width check
-  int kprev = 0, wide_cols = 0, kref_prev = 0;
+  int kprev = 0, wide_cols = 0, kref_prev = 0, fused_c0 = -1;
   HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
   for (; rounds < 2 * a.max_rounds + 2; ++rounds) {
     if (prev_run) {
@@ -947,15 +948,19 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         // (a.W is still last round's window: those columns are in that round's XH rows already); one launch per
         // k-group region: its rows share a last active bound
         const int c0 = (a.W < h->np && (h->np - a.W) % 128 == 0) ? a.W : 0;
+        fused_c0 = (h->np - c0) % 128 == 0 ? c0 : -1;     // the fused kernel's 128-column tiles fit: check in the GEMM's epilogue
         for (int g = 0; g < ASM_NKG; ++g) {
           const size_t r0 = (size_t)g * a.wcap * h->np;
-          gemm64(h, h->asm_xhw + r0 + c0, h->np, h->asm_lamw + r0, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_run + 127) / 128) * 128,
-                 h->np - c0, h->np, nullptr, 0, h->asm_counters + ASM_CNT_WKMAX + g, h->asm_counters + ASM_CNT_WIDEG + g);
+          if (fused_c0 >= 0)
+            hipLaunchKernelGGL(asm_wide_gemm_k, dim3((h->np - c0) / 128, (prev_run + 127) / 128), dim3(256), GEMM64_128_LDS, s, a, g, c0);
+          else
+            gemm64(h, h->asm_xhw + r0 + c0, h->np, h->asm_lamw + r0, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_run + 127) / 128) * 128,
+                   h->np - c0, h->np, nullptr, 0, h->asm_counters + ASM_CNT_WKMAX + g, h->asm_counters + ASM_CNT_WIDEG + g);
         }
         wide_cols = h->np - c0;
       }
       EvScope es(h, 6, 0.0);
-      hipLaunchKernelGGL(asm_wide_k, dim3(prev_run, ASM_NKG), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(asm_wide_k, dim3(prev_run, ASM_NKG), dim3(256), a.max_active * sizeof(double), s, a, fused_c0);
     }
     kref_prev = a.kref;
     a.kref = kprev;
@@ -1182,6 +1187,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32b_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32B_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_tile32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_TILE32_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_kdyn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
@@ -1228,7 +1234,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->asm_pool = h->seg_max >= 4096 ? 1024 : 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka); A_(h->H32, (size_t)np * np);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
-  A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G);
+  A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G); A_(h->asm_wflag, G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 1) * G);
   A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 3 * G);

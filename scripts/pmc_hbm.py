@@ -22,9 +22,12 @@ def load(d, counter):
     return acc, t
 
 root, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_sha: the profile is only quoted by bench.py for the kernel sources it was taken on)
 fe, tf = load(root + "/fetch", "FETCH_SIZE")
 wr, tw = load(root + "/write", "WRITE_SIZE")
-res = {"command": cmd, "correction": "FETCH_SIZE x2 x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM)", "kernels": {}}
+res = {"command": cmd, "csrc_sha": bench.csrc_sha(), "correction": "FETCH_SIZE x2 x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM)", "kernels": {}}
 for n, (calls, v) in sorted(fe.items(), key=lambda kv: -kv[1][1]):
     if "nnmpc" not in n: continue
     fb = v * 2 * 1024; wb = wr.get(n, [0, 0.0])[1] * 1024; ms = tf.get(n, 0.0)
