@@ -600,8 +600,11 @@ template <class T> __device__ __forceinline__ T rowsum16(T x) {
 template <class T> __device__ __forceinline__ T xsum4(T x) { return AsmNum<T>::swap32(AsmNum<T>::swap16(x)); }
 
 // tiles of the first NL block columns kept in LDS; LDS elements per wave
+#ifndef ASM_NL_OF_8
+#define ASM_NL_OF_8 2              // (scripts/micro/occ_probe.hip overrides this to try other register / LDS splits)
+#endif
 template <class T> __host__ __device__ constexpr int asm_nl(int mb) {
-  return mb <= 7 ? 0 : (mb <= 9 ? 2 : 4);
+  return mb <= 7 ? 0 : (mb == 8 ? ASM_NL_OF_8 : (mb <= 9 ? 2 : 4));
 }
 template <class T> __host__ __device__ constexpr int asm_nlt(int mb) { return asm_nl<T>(mb) * (mb - 1) - asm_nl<T>(mb) * (asm_nl<T>(mb) - 1) / 2; }
 template <class T> __host__ __device__ constexpr int asm_rw(int mb) { return 2 * ASM_TS + 2 * mb * 16 + asm_nlt<T>(mb) * 256; }
@@ -632,17 +635,18 @@ __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane) {
     asm volatile("" : "+v"(a));                            // keeps the 16 loads unconditional and back to back (the
     x[k] = inv_half ? (k == row ? T(1) : T(0)) : a;        // select would otherwise become 16 divergent branches)
   }
-  T dmin = T(1);                                           // smallest pivot: kept beside the chain, tested once at the end
 #pragma unroll
   for (int cc = 0; cc < 16; ++cc) {
     const T dd = N::rdlane(x[cc], cc);
-    dmin = dd < dmin ? dd : dmin;
     const T w = x[cc] * N::rsq(dd);                        // L[row][cc]  |  Y[cc][row]
     x[cc] = w;
 #pragma unroll
     for (int c2 = cc + 1; c2 < 16; ++c2) x[c2] -= w * N::rdlane(w, c2);
   }
-  const int bad = !(dmin > T(0));                          // not positive definite in this precision (the rest is NaN)
+  // Not positive definite in this precision <=> some pivot was <= 0 (or NaN): its rsq is NaN / Inf, which every later
+  // column inherits through the updates -- the LAST diagonal entry L[15][15] (lane 15) then fails "> 0".  One test
+  // instead of a running minimum beside the chain (which cost a v_writelane and a compare per pivot).
+  const int bad = !(N::rdlane(x[15], 15) > T(0));
   if (lane >= 48) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = x[k];
@@ -652,6 +656,18 @@ __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane) {
 
 __device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane) { return asm_diag16<double>(Tk, Yt, lane); }
 
+
+// In-kernel phase stamps of ONE wave (scripts/micro only: -DASM_STAMPS): shader-clock reads at the phase boundaries of
+// wave 0 of workgroup ASM_STAMP_WG, dumped to a device array.  Compiles to nothing otherwise.
+#ifdef ASM_STAMPS
+__device__ unsigned long long asm_stamp_buf[64];
+#ifndef ASM_STAMP_WG
+#define ASM_STAMP_WG 0
+#endif
+#define ASM_STAMP(i) do { if (wg == ASM_STAMP_WG && wave == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) asm_stamp_buf[i] = t_; } } while (0)
+#else
+#define ASM_STAMP(i) do { } while (0)
+#endif
 
 template <class T, int MB, int WPB>
 __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg) {
@@ -676,12 +692,19 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
   const int* idx = d.idxg + (size_t)p * d.max_active;
   const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
   if (m <= 0) return;
-  // ---- rhs -> LDS (read back block by block: registers are the scarce resource here)
+  ASM_STAMP(0);
+  // ---- active indices and rhs -> LDS (read back block by block: registers are the scarce resource here).  The index
+  // list goes through LDS because every later use of an index is the ADDRESS of a gather: read from global memory it
+  // would sit in the same in-order vmcnt queue as the gathers before it, and each block column of the gather would
+  // wait for all the loads of the previous one (measured: 26 k of the wave's 85 k cycles went into ISSUING the gather).
+  int* ix = reinterpret_cast<int*>(ys);                    // [MB * 16] (ys is not written before the factorisation)
   for (int i = lane; i < MB * 16; i += 64) {
     const int a = idx[min(i, m - 1)], k = a % d.nu;
+    ix[i] = a;
     const double v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
     rv[i] = i < m ? (T)v : T(0);
   }
+  ASM_FENCE();
   // ---- gather: t(I,J)[r] = -S[16 I + li][16 J + kr(lq, r)], read as Pinv[row of (J, lq, r)][col of (I, li)].
   // The not yet factored tiles hold MINUS the Schur complement, so the trailing update is a plain
   // accumulation (the MFMAs have no negate modifier; a VALU negation would cost a pass over the operands).
@@ -689,19 +712,22 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
   {
     int gcol[MB];                                          // Pinv index of active bound 16 I + li
 #pragma unroll
-    for (int I = 0; I < MB; ++I) gcol[I] = idx[min(16 * I + li, m - 1)];
+    for (int I = 0; I < MB; ++I) gcol[I] = ix[16 * I + li];            // (entries beyond m repeat the last index)
 #pragma unroll
     for (int J = 0; J < MB; ++J) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gj = 16 * J + N::kr(lq, r);
         using HT = typename std::conditional<N::F32, float, double>::type;
-        const HT* Hr = (N::F32 ? reinterpret_cast<const HT*>(d.H32) : reinterpret_cast<const HT*>(d.H)) + (size_t)idx[min(gj, m - 1)] * d.np;
+        const HT* Hr = (N::F32 ? reinterpret_cast<const HT*>(d.H32) : reinterpret_cast<const HT*>(d.H)) + (size_t)ix[gj] * d.np;
 #pragma unroll
         for (int I = J; I < MB; ++I) {                     // unconditional (clamped) loads, then select
           const int gi = 16 * I + li;
           const HT v = Hr[gcol[I]];
-          const T e = (gi < m && gj < m) ? (T)(-v) : (gi == gj ? T(-1) : T(0));
+          // a class of MB >= 5 blocks holds sets with 16 (MB - 1) < m <= 16 MB: only the last block row / column can
+          // reach beyond m (padding = identity); the other tiles need no select
+          const bool edge = MB <= 4 || I == MB - 1;
+          const T e = !edge ? (T)(-v) : ((gi < m && gj < m) ? (T)(-v) : (gi == gj ? T(-1) : T(0)));
           if (J < NL && I > J) lt[slot(I, J) * 256 + r * 64] = e;
           else C[asm_tix(I, J)][r] = e;
         }
@@ -709,6 +735,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  ASM_STAMP(1);                                            // (the gathered values are not waited for yet)
   T ps[MB];                                                // lane-local partial sums of  sum_J L(I,J) y_J
 #pragma unroll
   for (int I = 0; I < MB; ++I) ps[I] = T(0);
@@ -739,11 +766,14 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
 #pragma unroll
   for (int r = 0; r < 4; ++r) dt[li * 17 + N::kr(lq, r)] = -C[asm_tix(0, 0)][r];
   ASM_FENCE();
+  ASM_STAMP(2);
   bad |= asm_diag16<T>(dt, Yt, lane);
   ASM_FENCE();
+  ASM_STAMP(3);
   asm_sfor<0, MB>([&](auto Kc) {
     constexpr int K = decltype(Kc)::value;
     __builtin_amdgcn_sched_barrier(0);
+    ASM_STAMP(4 + 3 * K);
     T yf[4];                                               // fragments of -Y_K
     V4 Yc;                                                 // Y_K' in C layout: [li][kr] of Y' = Y[kr(lq, r)][li]
 #pragma unroll
@@ -781,6 +811,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
 #pragma unroll
       for (int r = 0; r < 4; ++r) ps[I] += acc[r] * yq[r];
     }
+    ASM_STAMP(5 + 3 * K);                                  // (TRSM of column K issued)
     if constexpr (K + 1 < MB) {
       trail(Kc, asm_ic<K + 1>{}, asm_ic<K + 1>{}, P);      // the next diagonal tile first ...
 #pragma unroll
@@ -795,10 +826,12 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
           if constexpr (!(I == K + 1 && J == K + 1)) trail(Kc, Jc, Ic, P);
         });
       });
+      ASM_STAMP(6 + 3 * K);                                // (trailing update issued)
       bad |= asm_diag16<T>(dt, Yt, lane);
       ASM_FENCE();
     }
   });
+  ASM_STAMP(40);
   if (bad) {
     // f32: S is not positive definite in this precision -- this round is void (asm_update_k skips the problem,
     // its LAM row is still zero), the next one runs in fp64.  fp64: hand the problem to the PDIP path.
@@ -826,6 +859,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
     lam[K] = xsum4<T>(part);
     __builtin_amdgcn_sched_barrier(0);
   }
+  ASM_STAMP(41);
   using LT = typename std::conditional<N::F32, float, double>::type;   // f32 rounds: row of LAM32 (f32 GEMM)
   LT* lrow = (N::F32 ? (LT*)d.lam32 : (LT*)d.lam) + (size_t)d.row[p] * d.np;
 #pragma unroll

@@ -11,11 +11,22 @@
 using namespace nnmpc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
+// variant 3: ONE size class of the f32 register kernel at a chosen occupancy / LDS split (-DPROBE_MB=8 -DPROBE_OCC=3 -DASM_NL_OF_8=1)
+#ifdef PROBE_MB
+#ifndef PROBE_OCC
+#define PROBE_OCC 2
+#endif
+extern "C" __global__ __launch_bounds__(256, PROBE_OCC) void probe_k(AsmDev d) {
+  asm_lambda_reg<float, PROBE_MB, 4>(d, ASM_NBIN + PROBE_MB - 4, blockIdx.x);
+}
+#endif
+
 int main(int argc, char** argv) {
   const int m = argc > 1 ? atoi(argv[1]) : 112;
   const int nseg = argc > 2 ? atoi(argv[2]) : 14336;
   const int variant = argc > 3 ? atoi(argv[3]) : 0;      // 0 tile kernel, 1 register kernel (fp64), 2 register kernel (f32)
-  const int n = 512, np = 512, nu = 32, win = 416, max_active = 768;
+  const int n = 512, np = 512, nu = 32, max_active = 768;
+  const int win = argc > 4 ? atoi(argv[4]) : 416;         // the active indices are drawn from [0, win): win = m makes them contiguous
   std::mt19937_64 rng(1);
   std::normal_distribution<double> g(0.0, 1.0);
   std::vector<double> G((size_t)n * n), H((size_t)n * n);
@@ -59,6 +70,12 @@ int main(int argc, char** argv) {
   d.binlist = dbin; d.idxg = didx; d.mg = dmg;
   unsigned char *dprec, *dredo; CK(hipMalloc(&dprec, nseg)); CK(hipMemset(dprec, 0, nseg)); CK(hipMalloc(&dredo, nseg)); CK(hipMemset(dredo, 0, nseg));
   d.prec = dprec; d.redo = dredo;
+  {
+    std::vector<float> H32(H.size());
+    for (size_t i = 0; i < H.size(); ++i) H32[i] = (float)H[i];
+    float* dH32; CK(hipMalloc(&dH32, H32.size() * 4)); CK(hipMemcpy(dH32, H32.data(), H32.size() * 4, hipMemcpyHostToDevice));
+    d.H32 = dH32;
+  }
   float* dlam32; CK(hipMalloc(&dlam32, xunc.size() * 4)); CK(hipMemset(dlam32, 0, xunc.size() * 4)); d.lam32 = dlam32;
   unsigned char* drowk; CK(hipMalloc(&drowk, nseg)); CK(hipMemset(drowk, 0, nseg)); d.rowk = drowk;
   int* drow; CK(hipMalloc(&drow, nseg * 4)); CK(hipMemcpy(drow, list.data(), nseg * 4, hipMemcpyHostToDevice)); d.row = drow;
@@ -73,6 +90,14 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
+#ifdef PROBE_MB
+    if (variant == 3) {
+      static bool once = false;
+      const int lds = 4 * asm_rw<float>(PROBE_MB) * 4;
+      if (!once) { CK(hipFuncSetAttribute((const void*)probe_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+      hipLaunchKernelGGL(probe_k, dim3((nseg + 3) / 4), dim3(256), lds, 0, d);
+    } else
+#endif
     if (variant == 0) hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nseg), dim3(256), lds_tile, 0, d, bin);
     else if (variant == 2 && bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG32_LDS, 0, d);
     else if (variant == 2) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3((nseg + 3) / 4 + 2), dim3(256), ASM_REG32B_LDS, 0, d);
@@ -92,7 +117,7 @@ int main(int argc, char** argv) {
   double worst = 0.0;
   for (int pp = 0; pp < 2; ++pp) {
     const int p = pp == 0 ? 0 : nseg - 1;
-    if (variant == 2) {
+    if (variant == 2 || variant == 3) {
       std::vector<float> l32(np);
       CK(hipMemcpy(l32.data(), dlam32 + (size_t)p * np, np * 4, hipMemcpyDeviceToHost));
       for (int i = 0; i < np; ++i) lam[i] = l32[i];
@@ -105,6 +130,17 @@ int main(int argc, char** argv) {
       worst = std::max(worst, fabs(r));
     }
   }
+#ifdef ASM_STAMPS
+  {
+    unsigned long long st_[64];
+    CK(hipMemcpyFromSymbol(st_, HIP_SYMBOL(asm_stamp_buf), sizeof st_));
+    printf("stamps (cycles since wave start): rhs+gather issued %llu, first tile ready %llu, diag0 %llu\n", st_[1] - st_[0], st_[2] - st_[0], st_[3] - st_[2]);
+    for (int K = 0; K < 9 && st_[4 + 3 * K]; ++K)
+      printf("  column %d: start %llu  trsm-issued +%llu  trail-issued +%llu  (next column at +%llu)\n", K, st_[4 + 3 * K] - st_[0], st_[5 + 3 * K] - st_[4 + 3 * K],
+             st_[6 + 3 * K] > st_[5 + 3 * K] ? st_[6 + 3 * K] - st_[5 + 3 * K] : 0ull, st_[4 + 3 * (K + 1)] > st_[4 + 3 * K] ? st_[4 + 3 * (K + 1)] - st_[4 + 3 * K] : 0ull);
+    printf("  factor done %llu, backward substitution %llu\n", st_[40] - st_[0], st_[41] - st_[40]);
+  }
+#endif
   printf("variant %d m %d nseg %d: %.3f ms  (%.2f problems/us)  max residual %.2e  fallback %d\n", variant, m, nseg, best, nseg / (best * 1e3), worst, nfb);
   return 0;
 }
