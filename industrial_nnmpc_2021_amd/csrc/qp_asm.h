@@ -372,7 +372,7 @@ __device__ __forceinline__ double* asm_tile(double* T, int I, int J) { return T 
 
 #define ASM_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <class T> __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane);
+template <class T> __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane, const T* Id = nullptr);
 __device__ __noinline__ int asm_diag16_call(const double* Tk, double* Yt, int lane);
 
 // One workgroup, one problem: rA <- lam = (H_AA)^-1 (x_unc,A - b_A) for the set idx[0..m).  rA [>= 16 ceil(m/16)]
@@ -549,6 +549,7 @@ template <> struct AsmNum<double> {
   __device__ static __forceinline__ v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   __device__ static __forceinline__ double rdlane(double x, int l) { return rdlane_d(x, l); }
   __device__ static __forceinline__ double rsq(double x) { return rsqrt(x); }
+
   template <int CTRL> __device__ static __forceinline__ double dpp(double x) {
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
@@ -575,6 +576,7 @@ template <> struct AsmNum<float> {
   __device__ static __forceinline__ v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
   __device__ static __forceinline__ float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
   __device__ static __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
   template <int CTRL> __device__ static __forceinline__ float dpp(float x) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, false));
   }
@@ -623,18 +625,29 @@ __device__ __forceinline__ void asm_sfor(F&& f) {          // f(asm_ic<B>{}), ..
 // forward substitution L Y = I for the second.  Pivot and L[c2][cc] are wave-uniform (v_readlane from
 // lanes cc / c2), used once each, so they do not pile up in SGPRs.  16 live values per lane.
 // Tk: the tile in LDS (row-major, stride 17, read only); Yt receives Y (same layout).
+// Id (optional): an identity tile in LDS (same layout): the lanes of the inverse half then READ their unit vectors
+// instead of selecting them (one pointer select instead of 16 v_cndmask per tile).
 template <class T>
-__device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane) {
+__device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane, const T* Id) {
   using N = AsmNum<T>;
   const int row = lane & 15;
   const bool inv_half = lane >= 32;
   T x[16];
+  if (Id) {
+    const T* src = inv_half ? Id : Tk;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    T a = Tk[row * 17 + k];
-    asm volatile("" : "+v"(a));                            // keeps the 16 loads unconditional and back to back (the
-    x[k] = inv_half ? (k == row ? T(1) : T(0)) : a;        // select would otherwise become 16 divergent branches)
+    for (int k = 0; k < 16; ++k) x[k] = src[row * 17 + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      T a = Tk[row * 17 + k];
+      asm volatile("" : "+v"(a));                          // keeps the 16 loads unconditional and back to back (the
+      x[k] = inv_half ? (k == row ? T(1) : T(0)) : a;      // select would otherwise become 16 divergent branches)
+    }
   }
+  // (the broadcasts stay on v_readlane: the same sweep with ds_bpermute -- DS instructions, 47 % fewer vector
+  // instructions per tile -- ran 25 % SLOWER: the crossbar's latency sits in the pivot chain; so did a sweep shared by the
+  // four waves of a workgroup over DPP row_newbcast, behind two barriers per block column: +26 %)
 #pragma unroll
   for (int cc = 0; cc < 16; ++cc) {
     const T dd = N::rdlane(x[cc], cc);
@@ -682,6 +695,8 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
   T* ys = Yt + ASM_TS;                                     // y (forward result), [MB][16]
   T* rv = ys + MB * 16;                                    // right-hand side, [MB][16]
   T* lt = rv + MB * 16 + lane;                             // LDS-resident tiles: slot * 256 + r * 64 (+ lane)
+  T* idt = reinterpret_cast<T*>(sm_raw) + (size_t)WPB * asm_rw<T>(MB);   // identity tile (every wave writes all of it: same
+  for (int i = lane; i < ASM_TS; i += 64) idt[i] = (i / 17 == i % 17) ? T(1) : T(0);   // values, so no barrier is needed)
   auto slot = [](int I, int J) { return J * (MB - 1) - J * (J - 1) / 2 + I - J - 1; };   // tile (I,J), J < NL, I > J
   const int nitem = d.counters[asm_list_counter(list)];
   const int it = wg * WPB + wave;
@@ -713,17 +728,24 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
     int gcol[MB];                                          // Pinv index of active bound 16 I + li
 #pragma unroll
     for (int I = 0; I < MB; ++I) gcol[I] = ix[16 * I + li];            // (entries beyond m repeat the last index)
+    // addresses as 32-bit byte offsets from the (wave-uniform) base of Pinv: one v_add per load instead of 64-bit pointer
+    // arithmetic (np^2 entries of 4 / 8 bytes stay below 2^32 for every n the library accepts: np <= 23 k)
+    using HT0 = typename std::conditional<N::F32, float, double>::type;
+    const char* const Hbase = N::F32 ? reinterpret_cast<const char*>(d.H32) : reinterpret_cast<const char*>(d.H);
+    unsigned gco[MB];
+#pragma unroll
+    for (int I = 0; I < MB; ++I) gco[I] = (unsigned)gcol[I] * (unsigned)sizeof(HT0);
 #pragma unroll
     for (int J = 0; J < MB; ++J) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gj = 16 * J + N::kr(lq, r);
         using HT = typename std::conditional<N::F32, float, double>::type;
-        const HT* Hr = (N::F32 ? reinterpret_cast<const HT*>(d.H32) : reinterpret_cast<const HT*>(d.H)) + (size_t)ix[gj] * d.np;
+        const unsigned rowoff = (unsigned)ix[gj] * (unsigned)d.np * (unsigned)sizeof(HT);
 #pragma unroll
         for (int I = J; I < MB; ++I) {                     // unconditional (clamped) loads, then select
           const int gi = 16 * I + li;
-          const HT v = Hr[gcol[I]];
+          const HT v = *reinterpret_cast<const HT*>(Hbase + (rowoff + gco[I]));
           // a class of MB >= 5 blocks holds sets with 16 (MB - 1) < m <= 16 MB: only the last block row / column can
           // reach beyond m (padding = identity); the other tiles need no select
           const bool edge = MB <= 4 || I == MB - 1;
@@ -767,7 +789,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
   for (int r = 0; r < 4; ++r) dt[li * 17 + N::kr(lq, r)] = -C[asm_tix(0, 0)][r];
   ASM_FENCE();
   ASM_STAMP(2);
-  bad |= asm_diag16<T>(dt, Yt, lane);
+  bad |= asm_diag16<T>(dt, Yt, lane, idt);
   ASM_FENCE();
   ASM_STAMP(3);
   asm_sfor<0, MB>([&](auto Kc) {
@@ -827,7 +849,7 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
         });
       });
       ASM_STAMP(6 + 3 * K);                                // (trailing update issued)
-      bad |= asm_diag16<T>(dt, Yt, lane);
+      bad |= asm_diag16<T>(dt, Yt, lane, idt);
       ASM_FENCE();
     }
   });
@@ -883,7 +905,6 @@ __device__ __forceinline__ f32x4v_t tile_mma_nt32(const float* A, const float* B
   return acc;                                            // reg r of lane (li, lq): row 4 lq + r, column li
 }
 __device__ __forceinline__ float* asm_tile32(float* T, int I, int J) { return T + ((size_t)I * (I + 1) / 2 + J) * ASM_TS; }
-template <class T> __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane);
 
 // rA [>= 16 ceil(m/16)], Yt [ASM_TS], T [tiles] in LDS; returns 1 (to all threads) when H_AA is not positive definite in f32
 __device__ __forceinline__ int asm_tile_solve32(const AsmDev& d, int p, int m, const int* idx, float* rA, float* Yt, float* T, int* s_bad) {
@@ -1028,7 +1049,7 @@ __global__ __launch_bounds__(512, 1) void asm_lambda_tile32_k(AsmDev d) {
 // All register-resident fp64 size classes 0..5 in ONE launch (their workgroups are independent; separate
 // launches would serialise six tails): workgroup w walks the classes from the largest down and takes
 // four problems of the class its index falls into.  Grid: sum_b ceil(count_b / 4).
-constexpr int ASM_REG_LDS = 4 * asm_rw<double>(ASM_NREG + 3) * 8;  // bytes of dynamic LDS (largest class)
+constexpr int ASM_REG_LDS = (4 * asm_rw<double>(ASM_NREG + 3) + ASM_TS) * 8;  // bytes of dynamic LDS (largest class) + the identity tile
 __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
   int w = blockIdx.x;
 #define ASM_REG_CLASS(B)                                                   \
@@ -1042,7 +1063,7 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
   static_assert(ASM_NREG == 6, "one ASM_REG_CLASS line per register-resident size class");
 }
 // The 10- and 11-block classes (145..176 bounds): same code, two waves (problems) per workgroup.
-constexpr int ASM_REG2_LDS = 2 * asm_rw<double>(11) * 8;
+constexpr int ASM_REG2_LDS = (2 * asm_rw<double>(11) + ASM_TS) * 8;
 __global__ __launch_bounds__(128, 1) void asm_lambda_reg2_k(AsmDev d) {
   int w = blockIdx.x;
   {
@@ -1054,7 +1075,7 @@ __global__ __launch_bounds__(128, 1) void asm_lambda_reg2_k(AsmDev d) {
   static_assert(ASM_NBIN == 8 && ASM_MLDS == 176, "classes 6 and 7 are the 10- and 11-block sets");
 }
 // The f32 rounds of classes 0..5: two workgroups per CU (two waves per SIMD).
-constexpr int ASM_REG32_LDS = 4 * asm_rw<float>(ASM_NREG + 3) * 4;
+constexpr int ASM_REG32_LDS = (4 * asm_rw<float>(ASM_NREG + 3) + ASM_TS) * 4;
 __global__ __launch_bounds__(256, 2) void asm_lambda_reg32_k(AsmDev d) {
   int w = blockIdx.x;
 #define ASM_REG_CLASS(B)                                                            \
@@ -1068,7 +1089,7 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_reg32_k(AsmDev d) {
 }
 
 // ... and of classes 6, 7: four waves per workgroup, one workgroup per CU (LDS).
-constexpr int ASM_REG32B_LDS = 4 * asm_rw<float>(11) * 4;
+constexpr int ASM_REG32B_LDS = (4 * asm_rw<float>(11) + ASM_TS) * 4;
 __global__ __launch_bounds__(256, 1) void asm_lambda_reg32b_k(AsmDev d) {
   int w = blockIdx.x;
   {

@@ -1319,6 +1319,10 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
   if (!h || !Hinv || !Kunc) { set_error("nnmpc_qp_set_inverse: bad arguments"); return NNMPC_EINVAL; }
   HIPCHK(hipSetDevice(h->device));
   const int n = h->n, np = h->np, ka = h->ka, n_aug = h->n_aug;
+  if ((uint64_t)np * np * 8 >= (1ull << 32)) {            // the multiplier kernels address Pinv with 32-bit byte offsets
+    set_error("nnmpc_qp_set_inverse: n = %d is too large for the active-set pass (n < 23168)", n);
+    return NNMPC_EINVAL;
+  }
   std::vector<double> hh((size_t)np * np, 0.0), kk((size_t)np * ka, 0.0);
   for (int r = 0; r < n; ++r) {
     for (int c = 0; c < n; ++c) hh[(size_t)r * np + c] = 0.5 * (Hinv[(size_t)r * n + c] + Hinv[(size_t)c * n + r]);

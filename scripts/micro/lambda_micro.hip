@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
 #ifdef PROBE_MB
     if (variant == 3) {
       static bool once = false;
-      const int lds = 4 * asm_rw<float>(PROBE_MB) * 4;
+      const int lds = (4 * asm_rw<float>(PROBE_MB) + ASM_TS) * 4;
       if (!once) { CK(hipFuncSetAttribute((const void*)probe_k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
       hipLaunchKernelGGL(probe_k, dim3((nseg + 3) / 4), dim3(256), lds, 0, d);
     } else
