@@ -598,6 +598,36 @@ template <class T> __device__ __forceinline__ T rowsum16(T x) {
   x += N::template dpp<0x140>(x);       // row_mirror
   return x;
 }
+// Four row sums at once.  Generic: four rowsum16.  f32: the four chains interleaved by hand as v_add_f32_dpp (the DPP
+// operand folded into the add; hipcc emits v_mov_b32_dpp + v_add_f32 + s_nop 1 per step -- 240 moves and ~160 nops per
+// problem).  A DPP read needs two wait states after the vector write of its source: the three other chains' adds sit in
+// between, so no s_nop is needed inside the block; the one in front covers whatever wrote the inputs.
+template <class T> __device__ __forceinline__ void rowsum16x4(T (&v)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = rowsum16<T>(v[r]);
+}
+template <> __device__ __forceinline__ void rowsum16x4<float>(float (&v)[4]) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
 // sum over the four lane rows (lanes l, l^16, l^32, l^48), result in all of them
 template <class T> __device__ __forceinline__ T xsum4(T x) { return AsmNum<T>::swap32(AsmNum<T>::swap16(x)); }
 
@@ -805,7 +835,8 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
     const T tK = rv[16 * K + li] - (K ? xsum4<T>(ps[K]) : T(0));
     T yq[4];                                               // y_K[kr(lq, r)]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) yq[r] = rowsum16<T>(Yc[r] * tK);
+    for (int r = 0; r < 4; ++r) yq[r] = Yc[r] * tK;
+    rowsum16x4<T>(yq);
     if (li == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ys[16 * K + N::kr(lq, r)] = yq[r];
@@ -867,17 +898,16 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
 #pragma unroll
   for (int K = MB - 1; K >= 0; --K) {
     T part = T(0);
+    T s4[4] = {T(0), T(0), T(0), T(0)};                    // (sum_I L(I,K)' lam_I)[kr(lq, r)], summed over li
+    if (K < MB - 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      T tt = ys[16 * K + N::kr(lq, r)];
-      if (K < MB - 1) {
-        T s4 = T(0);                                       // (sum_I L(I,K)' lam_I)[kr(lq, r)], summed over li
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int I = K + 1; I < MB; ++I) s4 += (K < NL ? lt[slot(I, K) * 256 + r * 64] : C[asm_tix(I, K)][r]) * lam[I];
-        tt -= rowsum16<T>(s4);
-      }
-      part += C[asm_tix(K, K)][r] * tt;                    // Y_K[kr(lq, r)][li] tt[kr(lq, r)]
+        for (int I = K + 1; I < MB; ++I) s4[r] += (K < NL ? lt[slot(I, K) * 256 + r * 64] : C[asm_tix(I, K)][r]) * lam[I];
+      rowsum16x4<T>(s4);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part += C[asm_tix(K, K)][r] * (ys[16 * K + N::kr(lq, r)] - s4[r]);   // Y_K[kr(lq, r)][li] tt[kr(lq, r)]
     lam[K] = xsum4<T>(part);
     __builtin_amdgcn_sched_barrier(0);
   }
