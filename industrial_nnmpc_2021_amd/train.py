@@ -102,7 +102,7 @@ def train_nn_controller(model, data, *, epochs=1500, batch_size=2048, validation
             opt.zero_grad(set_to_none=True)
             loss.backward()
             opt.step()
-            run += float(loss) * idx.numel()
+            run += float(loss.detach()) * idx.numel()
         model.eval()
         with torch.no_grad():
             vl = float(torch.mean((model(va["x"], va["uprev"], va["xs"], va["us"]) - va["u"]) ** 2)) if nval else run / ntr
