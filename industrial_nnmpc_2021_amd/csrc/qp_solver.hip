@@ -948,7 +948,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         // (a.W is still last round's window: those columns are in that round's XH rows already); one launch per
         // k-group region: its rows share a last active bound
         const int c0 = (a.W < h->np && (h->np - a.W) % 128 == 0) ? a.W : 0;
-        fused_c0 = (h->np - c0) % 128 == 0 ? c0 : -1;     // the fused kernel's 128-column tiles fit: check in the GEMM's epilogue
+        static const bool no_fuse = getenv("NNMPC_NO_FUSED_WIDE") != nullptr;   // diagnostics: A/B of the fused epilogue
+        fused_c0 = ((h->np - c0) % 128 == 0 && !no_fuse) ? c0 : -1;     // the fused kernel's 128-column tiles fit: check in the GEMM's epilogue
         for (int g = 0; g < ASM_NKG; ++g) {
           const size_t r0 = (size_t)g * a.wcap * h->np;
           if (fused_c0 >= 0)
