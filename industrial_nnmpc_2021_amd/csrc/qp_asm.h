@@ -939,7 +939,11 @@ __device__ __forceinline__ float* asm_tile32(float* T, int I, int J) { return T 
 // rA [>= 16 ceil(m/16)], Yt [ASM_TS], T [tiles] in LDS; returns 1 (to all threads) when H_AA is not positive definite in f32
 __device__ __forceinline__ int asm_tile_solve32(const AsmDev& d, int p, int m, const int* idx, float* rA, float* Yt, float* T, int* s_bad) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef ASM_STAMPS
+  const int wg = blockIdx.x;
+#endif
   __syncthreads();
+  ASM_STAMP(48);
   if (tid == 0) *s_bad = 0;
   const size_t o = (size_t)p * d.np;
   const unsigned char* st = d.st + (size_t)p * d.n;
@@ -980,13 +984,19 @@ __device__ __forceinline__ int asm_tile_solve32(const AsmDev& d, int p, int m, c
     }
   }
   __syncthreads();
+  // Two barriers per block column: [TRSM of column K by all waves] | [wave 0: its tile (K+1, K+1) of the trailing update,
+  // Y_K' saved for the solves, then the NEXT diagonal step -- the long dependent chain -- while waves 1..7 share the rest
+  // of the trailing update].  (The first version ran diagonal step, TRSM and trailing update one after the other behind
+  // four barriers: the diagonal steps alone, seven waves waiting, were 45 % of the factorisation.)
+  ASM_STAMP(49);
+  if (wave == 0) {
+    const int bad = asm_diag16<float>(asm_tile32(T, 0, 0), Yt, lane);
+    if (bad && lane == 0) *s_bad = 1;
+  }
+  __syncthreads();
+  ASM_STAMP(50);
   for (int K = 0; K < mb; ++K) {
     float* TKK = asm_tile32(T, K, K);
-    if (wave == 0) {
-      const int bad = asm_diag16<float>(TKK, Yt, lane);
-      if (bad && lane == 0) *s_bad = 1;
-    }
-    __syncthreads();
     for (int I = K + 1 + wave; I < mb; I += 8) {         // TRSM: T(I,K) <- T(I,K) Y'   (eight waves)
       float* TIK = asm_tile32(T, I, K);
       const f32x4v_t acc = tile_mma_nt32(TIK, Yt, lane);
@@ -994,60 +1004,85 @@ __device__ __forceinline__ int asm_tile_solve32(const AsmDev& d, int p, int m, c
       for (int r = 0; r < 4; ++r) TIK[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = acc[r];
     }
     __syncthreads();
-    {
+    if (wave == 0) {
+      if (lane < 16) {                                     // Y_K' into the upper part of T(K,K) for the solves
+        const int row = lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k >= row) TKK[row * 17 + k] = Yt[k * 17 + row];
+      }
+      if (K + 1 < mb) {
+        const f32x4v_t acc = tile_mma_nt32(asm_tile32(T, K + 1, K), asm_tile32(T, K + 1, K), lane);
+        float* Tn = asm_tile32(T, K + 1, K + 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tn[(4 * (lane >> 4) + r) * 17 + (lane & 15)] -= acc[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile and the saved Y' are in LDS before the sweep reads / overwrites
+        const int bad = asm_diag16<float>(Tn, Yt, lane);
+        if (bad && lane == 0) *s_bad = 1;
+      }
+    } else {
       int b = 0;
       for (int I = K + 1; I < mb; ++I)
-        for (int J = K + 1; J <= I; ++J, ++b) {
-          if ((b & 7) != wave) continue;
+        for (int J = K + 1; J <= I; ++J) {
+          if (I == K + 1) continue;                        // (K+1, K+1): wave 0
+          if ((b++ % 7) + 1 != wave) continue;
           const f32x4v_t acc = tile_mma_nt32(asm_tile32(T, I, K), asm_tile32(T, J, K), lane);
           float* TIJ = asm_tile32(T, I, J);
 #pragma unroll
           for (int r = 0; r < 4; ++r) TIJ[(4 * (lane >> 4) + r) * 17 + (lane & 15)] -= acc[r];
         }
     }
-    if (wave == 0 && lane < 16) {                          // Y_K' into the upper part of T(K,K) for the solves
-      const int row = lane;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) if (k >= row) TKK[row * 17 + k] = Yt[k * 17 + row];
-    }
     __syncthreads();
   }
+  ASM_STAMP(51);
   if (*s_bad) return 1;
-  if (wave == 0) {
+  // ---- substitutions, column oriented, all eight waves (one wave alone spent 29 % of the kernel here): as soon as y_K
+  // (lam_K) is known every wave takes it out of the right-hand sides of its share of the remaining block rows.
+  {
     const int i = lane & 15, kq = lane >> 4;
-    for (int K = 0; K < mb; ++K) {                       // forward
-      float t = 0.f;
-      for (int J = 0; J < K; ++J) {
-        const float* TKJ = asm_tile32(T, K, J);
+    for (int K = 0; K < mb; ++K) {                       // forward:  L y = r
+      if (wave == 0) {                                   // y_K = Y_K t_K,  Y_K[i][k] (k <= i) stored at TKK[k][i]
+        const float* TKK = asm_tile32(T, K, K);
+        const float t = rA[16 * K + i];
+        float yv = t * TKK[i * 17 + i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t += TKJ[i * 17 + 4 * kq + k] * rA[16 * J + 4 * kq + k];
+        for (int k = 0; k < 16; ++k) { const float tk = __shfl(t, k); if (k < i) yv += TKK[k * 17 + i] * tk; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 16) rA[16 * K + i] = yv;
       }
-      t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-      t = rA[16 * K + i] - t;
-      const float* TKK = asm_tile32(T, K, K);
-      float yv = t * TKK[i * 17 + i];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { const float tk = __shfl(t, k); if (k < i) yv += TKK[k * 17 + i] * tk; }
-      if (lane < 16) rA[16 * K + i] = yv;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    for (int K = mb - 1; K >= 0; --K) {                  // backward
-      float t = 0.f;
-      for (int I = K + 1; I < mb; ++I) {
+      __syncthreads();
+      for (int I = K + 1 + wave; I < mb; I += 8) {       // r_I -= L(I,K) y_K
         const float* TIK = asm_tile32(T, I, K);
+        float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t += TIK[(4 * kq + k) * 17 + i] * rA[16 * I + 4 * kq + k];
+        for (int k = 0; k < 4; ++k) t += TIK[i * 17 + 4 * kq + k] * rA[16 * K + 4 * kq + k];
+        t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+        if (lane < 16) rA[16 * I + i] -= t;
       }
-      t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-      t = rA[16 * K + i] - t;
-      const float* TKK = asm_tile32(T, K, K);
-      float lv = t * TKK[i * 17 + i];
+      __syncthreads();
+    }
+    for (int K = mb - 1; K >= 0; --K) {                  // backward:  L' lam = y
+      if (wave == 0) {                                   // lam_K = Y_K' t_K,  Y_K[k][i] (k > i) stored at TKK[i][k]
+        const float* TKK = asm_tile32(T, K, K);
+        const float t = rA[16 * K + i];
+        float lv = t * TKK[i * 17 + i];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { const float tk = __shfl(t, k); if (k > i) lv += TKK[i * 17 + k] * tk; }
-      if (lane < 16) rA[16 * K + i] = lv;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int k = 0; k < 16; ++k) { const float tk = __shfl(t, k); if (k > i) lv += TKK[i * 17 + k] * tk; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 16) rA[16 * K + i] = lv;
+      }
+      __syncthreads();
+      for (int J = K - 1 - wave; J >= 0; J -= 8) {       // y_J -= L(K,J)' lam_K
+        const float* TKJ = asm_tile32(T, K, J);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += TKJ[(4 * kq + k) * 17 + i] * rA[16 * K + 4 * kq + k];
+        t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+        if (lane < 16) rA[16 * J + i] -= t;
+      }
+      __syncthreads();
     }
   }
+  ASM_STAMP(52);
   __syncthreads();
   return 0;
 }

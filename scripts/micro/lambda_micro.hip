@@ -60,10 +60,10 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dst, st.size())); CK(hipMemcpy(dst, st.data(), st.size(), hipMemcpyHostToDevice));
   CK(hipMalloc(&dstate, nseg * 4)); CK(hipMemset(dstate, 0, nseg * 4));
   int bin = max((m + 15) / 16, 4) - 4; if (bin >= ASM_NBIN) bin = ASM_NBIN - 1;
-  int cnt[ASM_NCNT] = {0}; cnt[4 + bin] = nseg; cnt[ASM_CNT_F32 + bin] = nseg;
+  int cnt[ASM_NCNT] = {0}; cnt[4 + bin] = nseg; cnt[ASM_CNT_F32 + bin] = nseg; cnt[ASM_CNT_BIG32] = nseg;
   CK(hipMalloc(&dcnt, sizeof cnt)); CK(hipMemcpy(dcnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
-  CK(hipMalloc(&dbin, (size_t)ASM_NLIST * nseg * 4));
-  for (int b = 0; b < ASM_NLIST; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dbin, (size_t)(ASM_NLIST + 1) * nseg * 4));
+  for (int b = 0; b <= ASM_NLIST; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&didx, idx.size() * 4)); CK(hipMemcpy(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&dmg, nseg * 4)); CK(hipMemcpy(dmg, mg.data(), nseg * 4, hipMemcpyHostToDevice));
   d.H = dH; d.lb = dlb; d.ub = dub; d.xunc = dxu; d.lam = dlam; d.st = dst; d.state = dstate; d.counters = dcnt;
@@ -90,6 +90,11 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
+    if (variant == 4) {                                  // f32 LDS-tile workgroup kernel (177..256 bounds)
+      static bool once4 = false;
+      if (!once4) { CK(hipFuncSetAttribute((const void*)asm_lambda_tile32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_TILE32_LDS)); once4 = true; }
+      hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(nseg, 4096)), dim3(512), ASM_TILE32_LDS, 0, d);
+    } else
 #ifdef PROBE_MB
     if (variant == 3) {
       static bool once = false;
@@ -117,7 +122,7 @@ int main(int argc, char** argv) {
   double worst = 0.0;
   for (int pp = 0; pp < 2; ++pp) {
     const int p = pp == 0 ? 0 : nseg - 1;
-    if (variant == 2 || variant == 3) {
+    if (variant == 2 || variant == 3 || variant == 4) {
       std::vector<float> l32(np);
       CK(hipMemcpy(l32.data(), dlam32 + (size_t)p * np, np * 4, hipMemcpyDeviceToHost));
       for (int i = 0; i < np; ++i) lam[i] = l32[i];
@@ -139,6 +144,7 @@ int main(int argc, char** argv) {
       printf("  column %d: start %llu  trsm-issued +%llu  trail-issued +%llu  (next column at +%llu)\n", K, st_[4 + 3 * K] - st_[0], st_[5 + 3 * K] - st_[4 + 3 * K],
              st_[6 + 3 * K] > st_[5 + 3 * K] ? st_[6 + 3 * K] - st_[5 + 3 * K] : 0ull, st_[4 + 3 * (K + 1)] > st_[4 + 3 * K] ? st_[4 + 3 * (K + 1)] - st_[4 + 3 * K] : 0ull);
     printf("  factor done %llu, backward substitution %llu\n", st_[40] - st_[0], st_[41] - st_[40]);
+    if (st_[52]) printf("  tile32: rhs+gather %llu, first diagonal step %llu, factorisation %llu, substitutions %llu\n", st_[49] - st_[48], st_[50] - st_[49], st_[51] - st_[50], st_[52] - st_[51]);
   }
 #endif
   printf("variant %d m %d nseg %d: %.3f ms  (%.2f problems/us)  max residual %.2e  fallback %d\n", variant, m, nseg, best, nseg / (best * 1e3), worst, nfb);
