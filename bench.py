@@ -678,7 +678,10 @@ def main():
     if args.workload == "chains":
         out = chains_leg(ctx, "cdu", args.batch or 149, max(args.steps, 8))
         if rank == 0:
-            print(json.dumps(dict({"metric": "lock-step closed-loop chain steps/sec (CDU size)"}, **out, **common)))
+            line = {"metric": "lock-step closed-loop chain steps/sec (CDU size)"}
+            line.update(common)
+            line.update(out)                                  # (chains' own "steps" = simulation steps per chain)
+            print(json.dumps(line))
         return
 
     # cdu: BASELINE.json configs[2] "100k sampled x0, 1 MI355X"; at 8 GPUs configs[3] "1M sampled x0 over 8 GPUs" = 125 000 each

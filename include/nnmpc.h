@@ -75,6 +75,9 @@ typedef struct {
                                 results are accepted); < 0 = fp64 from the first round */
   int32_t seg_max;           /* problems per segment (one lock-step pass; ~0.3 MB of workspace each at n = 4480);
                                 0 = as many as a quarter of the free HBM holds (at most 2^20) */
+  int32_t asm_tail_batch;    /* a call (segment) of at most this many problems is finished on the device from the start
+                                (asm_tail_k, one workgroup per problem, no lock-step rounds): the chains of a task, a
+                                controller's single QP; 0 = 256 (the most the kernel's slabs hold), < 0 = never */
   float ipm_tol;             /* PDIP exit, objective scaled by 1/median(diag P):
                                 |r_d|_inf and mu <= tol*max(1,|q|_inf); 0 = 1e-2 */
   double refine_tol;         /* PCG exit: |step|_inf <= tol*max(1,|x|_inf); 0 = 1e-10 */

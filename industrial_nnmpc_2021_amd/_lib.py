@@ -16,7 +16,7 @@ class QpOpts(C.Structure):
                 ("max_polish_rounds", C.c_int32), ("max_refine", C.c_int32),
                 ("max_rounds", C.c_int32), ("sub_steps", C.c_int32), ("stale_max_changes", C.c_int32),
                 ("stale_cg_limit", C.c_int32), ("method", C.c_int32), ("asm_max_active", C.c_int32),
-                ("asm_max_rounds", C.c_int32), ("asm_f32_rounds", C.c_int32), ("seg_max", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
+                ("asm_max_rounds", C.c_int32), ("asm_f32_rounds", C.c_int32), ("seg_max", C.c_int32), ("asm_tail_batch", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
                 ("bound_tol", C.c_double)]
 
 

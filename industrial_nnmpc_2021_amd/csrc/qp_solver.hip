@@ -940,7 +940,20 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   int prev_run = 0;                                     // upper bound of the problems awaiting the full-width check
   int kprev = 0, wide_cols = 0, kref_prev = 0, fused_c0 = -1;
   HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
-  for (; rounds < 2 * a.max_rounds + 2; ++rounds) {
+  const bool tail_only = h->opts.asm_tail_batch >= 0 && nprob <= std::min(std::min(h->asm_pool, 256), h->opts.asm_tail_batch ? h->opts.asm_tail_batch : 256);
+  if (tail_only) {
+    // A call of at most 256 problems -- the lock-step chains of a task, a controller's single QP -- is finished on the
+    // device from the start (asm_tail_k: count -> fp64 solve -> x over all columns -> exchange rule, one workgroup per
+    // problem): lock-step rounds would be eight launches and a host read-back each for a handful of workgroups.
+    EvScope es(h, 4, 0.0);
+    hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
+    const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_AREA) * 8 + ((h->n + 15) / 16) * 16 + ASM_TAIL_EXTRA;
+    hipLaunchKernelGGL(asm_tail_k, dim3(nprob), dim3(256), lds_tail, s, a, a.max_rounds);
+    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(stream_sync(s));
+    h->stats.asm_rounds += 1;
+  }
+  for (; !tail_only && rounds < 2 * a.max_rounds + 2; ++rounds) {
     if (prev_run) {
       // problems that settled inside last round's column window: all columns of x, once
       {

@@ -31,7 +31,7 @@ class BatchedBoxQP:
 
     def __init__(self, P, tq, nu, *, Kunc="auto", method="auto", max_batch=1024, nb=0, ipm_tol=0.0,
                  max_rounds=0, max_ipm_iters=0, max_polish_rounds=0, max_refine=0, sub_steps=0, stale_max_changes=0, stale_cg_limit=0, asm_max_active=0,
-                 asm_max_rounds=0, asm_f32_rounds=0, seg_max=0):
+                 asm_max_rounds=0, asm_f32_rounds=0, seg_max=0, asm_tail_batch=0):
         lib = _lib.load()
         P = np.ascontiguousarray(P, dtype=np.float64)
         tq = np.ascontiguousarray(tq, dtype=np.float64)
@@ -60,7 +60,8 @@ class BatchedBoxQP:
                            max_polish_rounds=max_polish_rounds, max_refine=max_refine,
                            max_rounds=max_rounds, sub_steps=sub_steps, stale_max_changes=stale_max_changes,
                            stale_cg_limit=stale_cg_limit, method=meth, asm_max_active=asm_max_active,
-                           asm_max_rounds=asm_max_rounds, asm_f32_rounds=asm_f32_rounds, seg_max=seg_max, ipm_tol=ipm_tol, refine_tol=0.0, bound_tol=0.0)
+                           asm_max_rounds=asm_max_rounds, asm_f32_rounds=asm_f32_rounds, seg_max=seg_max, asm_tail_batch=asm_tail_batch,
+                           ipm_tol=ipm_tol, refine_tol=0.0, bound_tol=0.0)
         self._h = C.c_void_p()
         kp = Kunc.ctypes.data_as(C.c_void_p) if Kunc is not None else None
         _lib.check(lib.nnmpc_qp_create(C.byref(self._h), n, nu, n_aug,

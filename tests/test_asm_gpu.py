@@ -31,6 +31,9 @@ def _solve_ref(P, q, lb, ub, nu):
 def _qp(P, nu, **kw):
     from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
     n = P.shape[0]
+    # asm_tail_batch = -1: these small batches must go through the lock-step ROUND kernels (a call of <= 256 problems would
+    # otherwise be finished by the device tail kernel alone)
+    kw.setdefault("asm_tail_batch", -1)
     return BatchedBoxQP(P, np.eye(n), nu, method="asm", max_batch=128, **kw)   # tq = I: q = x0
 
 
@@ -151,9 +154,11 @@ def test_cycling_samples_of_the_ill_conditioned_plant():
     rows = np.array([836, 5564, 7016, 14320, 63988, 126862])
     x0 = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), 1)[rows]
     lb, ub = (pl["ulb"].T - s["us"])[rows], (pl["uub"].T - s["us"])[rows]
-    qp = BatchedBoxQP(P, tq, nu, nb=64, max_batch=128, method="asm")
+    qp = BatchedBoxQP(P, tq, nu, nb=64, max_batch=128, method="asm", asm_tail_batch=-1)
     out = qp.solve_batch(x0, lb, ub)
     assert (out["status"] == 0).all(), out["status"]
+    tail = BatchedBoxQP(P, tq, nu, nb=64, max_batch=128, method="asm").solve_batch(x0, lb, ub)     # ... and by the tail kernel alone
+    assert (tail["status"] == 0).all() and np.array_equal(tail["active"], out["active"]) and np.abs(tail["u"] - out["u"]).max() < 1e-9
     Ps = np.tril(P) + np.tril(P, -1).T
     for b in range(len(rows)):
         info = {"nu": nu}

@@ -14,6 +14,11 @@ def _qp(reg, **kw):
     return BatchedBoxQP(reg.P, reg.tq, reg.nu, max_batch=128, **kw)
 
 
+# "auto" finishes a call of <= 256 problems in the device tail kernel alone; "auto-rounds" forces the lock-step round kernels
+METHODS = {"auto": dict(method="auto"), "auto-rounds": dict(method="auto", asm_tail_batch=-1), "pdip": dict(method="pdip"),
+           "asm": dict(method="asm"), "asm-rounds": dict(method="asm", asm_tail_batch=-1)}
+
+
 def _exact(reg, x0, lb, ub):
     from oracle import qp as oqp
     n = reg.N * reg.nu
@@ -25,7 +30,7 @@ def _exact(reg, x0, lb, ub):
     return x, rows
 
 
-@pytest.mark.parametrize("method", ["auto", "pdip"])
+@pytest.mark.parametrize("method", ["auto", "auto-rounds", "pdip"])
 def test_tie_empty_and_saturated(method):
     pl, reg = regulator_problem("mini_cdu", seed=3)
     n, nu, N = reg.N * reg.nu, reg.nu, reg.N
@@ -45,14 +50,14 @@ def test_tie_empty_and_saturated(method):
     ub[4, 2] = xunc[2::nu].max() - 5e-10
     # rows 2, 3: the whole horizon saturated (huge initial state)
     x0[2] *= 200.0; x0[3] *= -300.0
-    qp = _qp(reg, method=method)
+    qp = _qp(reg, **METHODS[method])
     out = qp.solve_batch(x0, lb, ub)
     assert (out["status"] == 0).all(), out["status"]
     assert np.abs(out["u"][0]).max() < 1e-12 and not out["active"][0].any()
     assert not out["active"][1].any() and np.abs(out["u"][1] - xunc).max() < 1e-11
     # (the PDIP path's polish accepts a point within bound_tol of its bounds as free: on row 4 both answers satisfy the KKT
     # conditions to the stated slack; the default path starts from the bounds x_unc violates and keeps the bound)
-    assert out["active"][4].sum() == (1 if method == "auto" else out["active"][4].sum()) and out["active"][4].sum() <= 1
+    assert out["active"][4].sum() == (1 if method.startswith("auto") else out["active"][4].sum()) and out["active"][4].sum() <= 1
     for b in range(12):
         if b == 1 or (b == 4 and method == "pdip"):
             continue
@@ -63,7 +68,7 @@ def test_tie_empty_and_saturated(method):
     qp.close()
 
 
-@pytest.mark.parametrize("method", ["auto", "pdip"])
+@pytest.mark.parametrize("method", ["auto", "auto-rounds", "pdip"])
 def test_equal_bounds_fix_a_variable(method):
     """ulb == uub for one input: it is fixed over the whole horizon; the rest must be the optimum of the reduced problem."""
     from oracle import qp as oqp
@@ -72,7 +77,7 @@ def test_equal_bounds_fix_a_variable(method):
     s, x0, lb, ub = batch_inputs(pl, 6, 6, 2.5)
     fixed_val = 0.25
     lb[:, 1] = fixed_val; ub[:, 1] = fixed_val
-    qp = _qp(reg, method=method)
+    qp = _qp(reg, **METHODS[method])
     out = qp.solve_batch(x0, lb, ub)
     assert (out["status"] == 0).all(), out["status"]
     Ps = np.tril(reg.P) + np.tril(reg.P, -1).T
@@ -94,18 +99,18 @@ def test_equal_bounds_fix_a_variable(method):
     qp.close()
 
 
-@pytest.mark.parametrize("method", ["auto", "pdip", "asm"])
+@pytest.mark.parametrize("method", ["auto", "auto-rounds", "pdip", "asm", "asm-rounds"])
 def test_invalid_inputs_are_rejected_not_certified(method):
     pl, reg = regulator_problem("mini_cdu", seed=5)
     n = reg.N * reg.nu
     s, x0, lb, ub = batch_inputs(pl, 10, 7, 2.0)
-    good = _qp(reg, method=method).solve_batch(x0, lb, ub)
+    good = _qp(reg, **METHODS[method]).solve_batch(x0, lb, ub)
     x0b, lbb, ubb = x0.copy(), lb.copy(), ub.copy()
     x0b[1, 3] = np.nan
     x0b[4, 0] = np.inf
     lbb[6, 2], ubb[6, 2] = 0.5, -0.5                        # lb > ub
     ubb[8, 1] = np.nan
-    qp = _qp(reg, method=method)
+    qp = _qp(reg, **METHODS[method])
     out = qp.solve_batch(x0b, lbb, ubb)
     bad = [1, 4, 6, 8]
     assert (out["status"][bad] == 2).all(), out["status"]
@@ -116,11 +121,11 @@ def test_invalid_inputs_are_rejected_not_certified(method):
     qp.close()
 
 
-@pytest.mark.parametrize("method", ["auto", "pdip"])
+@pytest.mark.parametrize("method", ["auto", "auto-rounds", "pdip"])
 def test_first_move_output_equals_head_of_sequence(method):
     pl, reg = regulator_problem("mini_cdu", seed=6)
     s, x0, lb, ub = batch_inputs(pl, 300, 8, 2.5)           # more problems than resident slots
-    qp = _qp(reg, method=method)
+    qp = _qp(reg, **METHODS[method])
     full = qp.solve_batch(x0, lb, ub)
     first = qp.solve_batch(x0, lb, ub, first_move_only=True)
     assert first["u"].shape == (300, reg.nu)

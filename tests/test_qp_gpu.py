@@ -48,7 +48,8 @@ def test_solve_batch_matches_exact_optimum(name, seed, sx, nb, method):
     B = 48 if name.startswith("mini") else 12
     s, x0, lb, ub = batch_inputs(pl, B, seed + 10, sx)
     Uo, Ao = oracle_solve(reg, x0, lb, ub)
-    qp = _solver(reg, nb=nb, max_batch=128, method=method)
+    # (these batches of 12 / 48 problems: "auto" through the device tail kernel alone, "asm" through the lock-step rounds)
+    qp = _solver(reg, nb=nb, max_batch=128, method=method, **({"asm_tail_batch": -1} if method == "asm" else {}))
     out = qp.solve_batch(x0, lb, ub)
     assert (out["status"] == 0).all(), out["status"]
     if method == "pdip":
