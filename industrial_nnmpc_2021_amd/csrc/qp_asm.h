@@ -41,6 +41,7 @@ constexpr int ASM_NLIST = 2 * ASM_NBIN;   // lists in AsmDev::binlist: fp64 clas
                                           // f32 rounds of sets of ASM_MLDS + 1 .. ASM_BIG32 bounds (asm_lambda_tile32_k)
 constexpr int ASM_BIG32 = 256;            // largest set whose f32 rounds run with the tiles in LDS (16 x 16 lower f32 tiles, one
                                           // workgroup per problem); beyond: fp64 from the start, tiles in an L2 slab
+constexpr int ASM_CNT_BIG64 = 37;         // counters[37]: length of list ASM_NLIST + 1 (fp64 rounds of sets of 177 .. 256 bounds: asm_lambda_wg64_k)
 constexpr int ASM_CNT_BIG32 = 36;         // counters[36]: length of list ASM_NLIST
 constexpr int ASM_GRACE = 10;       // rounds without a new minimum of infeasible indices before single exchanges take over
 constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last asm_wide_k (statistics)
@@ -54,11 +55,11 @@ constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not ce
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
 // ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
 __host__ __device__ constexpr int asm_list_counter(int list) {
-  return list < ASM_NBIN ? 4 + list : (list < ASM_NLIST ? ASM_CNT_F32 + list - ASM_NBIN : ASM_CNT_BIG32);
+  return list < ASM_NBIN ? 4 + list : (list < ASM_NLIST ? ASM_CNT_F32 + list - ASM_NBIN : (list == ASM_NLIST ? ASM_CNT_BIG32 : ASM_CNT_BIG64));
 }
 constexpr int ASM_NKG = 3;         // rows of a round are ordered by the last active stage (groups: <= median, +1, beyond),
                                    // so that a 128-row block of the GEMM stops its k-loop at ITS last active bound
-constexpr int ASM_NSCAN = ASM_NLIST + 4 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, sum and max of
+constexpr int ASM_NSCAN = ASM_NLIST + 5 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, sum and max of
                                                         // the last active indices
 constexpr int ASM_CNT_ROWS32 = 15; // counters[15]: rows of LAM32 / XH32 handed out ([2]: rows of LAM / XH)
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
@@ -116,6 +117,7 @@ struct AsmDev {
   const double* xhw;               // [rows] = lamw * H, all columns
   int* wlist;                      // [ASM_NKG][wcap] those problems by k-group; their numbers are counters[ASM_CNT_WIDEG + g]
   int wcap;                        // rows per region of lamw / xhw / wlist
+  int use_wg;                      // sets of 145 .. 256 bounds go to the four-wave register kernels (qp_wg.h); 0: the single-wave / LDS-tile / slab kernels (A/B)
   int early64;                     // an f32 round that moves at most this many bounds is followed by an fp64 round (0: only a settled set is)
   int* wflag;                      // [nseg] set by asm_wide_gemm_k when a bound beyond the window is violated (cleared by asm_wide_k)
   double* work;                    // [nseg][3] statistics: flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels, flops of the f32 rounds
@@ -240,12 +242,13 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // the round) is reset here.
 // scan columns: 0 large sets, 1 + list, ASM_COL_ROW + prec * ASM_NKG + group (rows of LAM / LAM32), then the sum of
 // (last active index + 1) and the max index
-constexpr int ASM_COL_ROW = 2 + ASM_NLIST;
+constexpr int ASM_COL_ROW = 3 + ASM_NLIST;
+constexpr int ASM_WG_SETS = 256;   // largest set of the four-wave register kernels (qp_wg.h)
 __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + list otherwise
   run = p < d.nseg && d.state[p] == ASM_RUN;
   if (!run) return -1;
   const int m = d.mg[p];
-  if (m > ASM_MLDS) return (d.prec[p] == 0 && m <= ASM_BIG32) ? 1 + ASM_NLIST : 0;
+  if (m > ASM_MLDS) return (d.prec[p] == 0 && m <= ASM_BIG32) ? 1 + ASM_NLIST : ((d.use_wg && m <= ASM_WG_SETS) ? 2 + ASM_NLIST : 0);
   const int b = max((m + 15) / 16, 4) - 4;
   return 1 + (d.prec[p] == 0 ? ASM_NBIN + b : b);
 }
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   int kl = 0;
   if (run) { const int m = d.mg[p]; if (m > 0) kl = d.idxg[(size_t)p * d.max_active + m - 1]; }
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const bool r32 = col > ASM_NBIN;                           // solved in f32 this round: row of LAM32 / XH32
+  const bool r32 = col > ASM_NBIN && col <= 1 + ASM_NLIST;   // solved in f32 this round: row of LAM32 / XH32
   const int rcol = run ? ASM_COL_ROW + (r32 ? ASM_NKG : 0) + asm_kgroup(d, kl) : -1;
   int myrank = 0, myrow = 0;
 #pragma unroll
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
     if (lane == 0) wtot[ASM_COL_ROW + c][wave] = __popcll(mk);
   }
 #pragma unroll
-  for (int c = 0; c <= ASM_NLIST + 1; ++c) {
+  for (int c = 0; c <= ASM_NLIST + 2; ++c) {
     const unsigned long long mk = __ballot(col == c);
     if (col == c) myrank = __popcll(mk & lt);
     if (lane == 0) wtot[c][wave] = __popcll(mk);
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
       d.counters[ASM_CNT_WIDE + 1] = nw;
     } else if (tid == ASM_NSCAN - 2) d.counters[0] = total[tid];   // sum of (last active index + 1): algorithmic k of the GEMM
     else if (tid == 0) d.counters[1] = total[0];
-    else if (tid <= ASM_NLIST + 1) d.counters[asm_list_counter(tid - 1)] = total[tid];
+    else if (tid <= ASM_NLIST + 2) d.counters[asm_list_counter(tid - 1)] = total[tid];
     else if (tid == ASM_COL_ROW) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + g]; d.counters[2] = t; }
     else if (tid == ASM_COL_ROW + ASM_NKG) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + ASM_NKG + g]; d.counters[ASM_CNT_ROWS32] = t; }
   }
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   if (!run) return;
   const int m = d.mg[p];
   const int kl = m > 0 ? d.idxg[(size_t)p * d.max_active + m - 1] : 0;
-  const bool r32 = col > ASM_NBIN;
+  const bool r32 = col > ASM_NBIN && col <= 1 + ASM_NLIST;
   const int c0 = ASM_COL_ROW + (r32 ? ASM_NKG : 0), g = asm_kgroup(d, kl);
   int row = d.row[p] + base[c0 + g];
   for (int gg = 0; gg < g; ++gg) row += total[c0 + gg];      // rows ordered by group
@@ -658,6 +661,32 @@ __device__ __forceinline__ void asm_sfor(F&& f) {          // f(asm_ic<B>{}), ..
 // Tk: the tile in LDS (row-major, stride 17, read only); Yt receives Y (same layout).
 // Id (optional): an identity tile in LDS (same layout): the lanes of the inverse half then READ their unit vectors
 // instead of selecting them (one pointer select instead of 16 v_cndmask per tile).
+// The same sweep in three pieces (begin / 16 steps / end) for callers that interleave other work with the steps (qp_wg.h).
+template <class T> __device__ __forceinline__ void asm_diag16_begin(T (&x)[16], const T* Tk, const T* Id, int lane) {
+  const T* src = lane >= 32 ? Id : Tk;
+  const int row = lane & 15;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = src[row * 17 + k];
+}
+template <class T, int CC> __device__ __forceinline__ void asm_diag16_step(T (&x)[16]) {
+  using N = AsmNum<T>;
+  const T dd = N::rdlane(x[CC], CC);
+  const T w = x[CC] * N::rsq(dd);
+  x[CC] = w;
+#pragma unroll
+  for (int c2 = CC + 1; c2 < 16; ++c2) x[c2] -= w * N::rdlane(w, c2);
+}
+template <class T> __device__ __forceinline__ int asm_diag16_end(const T (&x)[16], T* Yt, int lane) {
+  using N = AsmNum<T>;
+  const int bad = !(N::rdlane(x[15], 15) > T(0));
+  if (lane >= 48) {
+    const int row = lane & 15;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Yt[k * 17 + row] = x[k];
+  }
+  return bad;
+}
+
 template <class T>
 __device__ __forceinline__ int asm_diag16(const T* Tk, T* Yt, int lane, const T* Id) {
   using N = AsmNum<T>;
@@ -1165,6 +1194,10 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg32b_k(AsmDev d) {
   }
   asm_lambda_reg<float, 10, 4>(d, ASM_NBIN + 6, w);
 }
+
+}  // namespace nnmpc
+#include "qp_wg.h"
+namespace nnmpc {
 
 // x from the GEMM result, fp64 KKT tests, next active set.  A problem whose set no longer changes
 // is certified right here when the verified inverse allows it:  with E1 = P Kunc + tq and

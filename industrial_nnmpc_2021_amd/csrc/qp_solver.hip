@@ -931,6 +931,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wflag = h->asm_wflag; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.ldu = h->ldu; a.nout = h->nout; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
+  { static const int wg = getenv("NNMPC_NO_WG") ? 0 : 1; a.use_wg = wg; }   // (the variable: diagnostics, A/B against the kernels it replaced)
   { static const int e64 = getenv("NNMPC_EARLY64") ? atoi(getenv("NNMPC_EARLY64")) : 4; a.early64 = e64; }   // (the variable: diagnostics, A/B of the rule)
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
   // asm_update_k / asm_wide_k of the same round
@@ -1033,14 +1034,19 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // workgroup each: long latency chains on a handful of CUs) beside it on the side stream.
       const int nreg2_wg = (cnt[4 + 6] + 1) / 2 + (cnt[4 + 7] + 1) / 2;
       const int nreg32b_wg = (cnt[ASM_CNT_F32 + 6] + 3) / 4 + (cnt[ASM_CNT_F32 + 7] + 3) / 4;
-      int nbig = cnt[1] + cnt[ASM_CNT_BIG32] + nreg2_wg + nreg32b_wg, nreg_wg = 0, nreg32_wg = 0;
+      // (use_wg, the default: sets of 177 .. 256 bounds, one workgroup of four or eight waves each -- qp_wg.h)
+      const int nwg64 = a.use_wg ? cnt[ASM_CNT_BIG64] : 0;
+      const int nwg32 = a.use_wg ? cnt[ASM_CNT_BIG32] : 0;
+      int nbig = cnt[1] + cnt[ASM_CNT_BIG32] + nreg2_wg + nreg32b_wg + nwg64, nreg_wg = 0, nreg32_wg = 0;
       for (int b = 0; b < ASM_NREG; ++b) { nreg_wg += (cnt[4 + b] + 3) / 4; nreg32_wg += (cnt[ASM_CNT_F32 + b] + 3) / 4; }
       if (nbig) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        if (nwg64) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nwg64), dim3(256), asm_wg_lds_bytes<double>(), h->stream2, a);
+        if (nwg32) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nwg32), dim3(256), asm_wg_lds_bytes<float>(), h->stream2, a);
         if (nreg2_wg) hipLaunchKernelGGL(asm_lambda_reg2_k, dim3(nreg2_wg), dim3(128), ASM_REG2_LDS, h->stream2, a);
         if (nreg32b_wg) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3(nreg32b_wg), dim3(256), ASM_REG32B_LDS, h->stream2, a);
-        if (cnt[ASM_CNT_BIG32]) hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(cnt[ASM_CNT_BIG32], 4096)), dim3(512), ASM_TILE32_LDS, h->stream2, a);
+        if (cnt[ASM_CNT_BIG32] && !a.use_wg) hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(cnt[ASM_CNT_BIG32], 4096)), dim3(512), ASM_TILE32_LDS, h->stream2, a);
         if (cnt[1]) hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream2, a, 0);
         HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       }
@@ -1251,7 +1257,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G); A_(h->asm_wflag, G);
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
-  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 1) * G);
+  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 2) * G);
   A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 3 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_

@@ -38,7 +38,7 @@ def _qp(P, nu, **kw):
 
 
 @pytest.mark.parametrize("f32_rounds", [0, -1])       # 0: rounds in f32 until the set settles, then fp64; -1: fp64 throughout
-@pytest.mark.parametrize("n_active_target", [20, 60, 72, 85, 98, 110, 122, 135, 145, 165, 200, 230])
+@pytest.mark.parametrize("n_active_target", [20, 60, 72, 85, 98, 110, 122, 135, 145, 150, 165, 180, 200, 212, 230])
 def test_size_classes(n_active_target, f32_rounds):
     """Sets of ~20 .. ~280 bounds (the couplings add ~20 % to the pushed ones): every kernel variant must
     reproduce the exact optimum and set."""
