@@ -57,6 +57,7 @@ constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not ce
 __host__ __device__ constexpr int asm_list_counter(int list) {
   return list < ASM_NBIN ? 4 + list : (list < ASM_NLIST ? ASM_CNT_F32 + list - ASM_NBIN : (list == ASM_NLIST ? ASM_CNT_BIG32 : ASM_CNT_BIG64));
 }
+__host__ __device__ constexpr int asm_list_of_counter(int c) { return c >= ASM_CNT_F32 ? ASM_NBIN + c - ASM_CNT_F32 : c - 4; }   // size-class lists only
 constexpr int ASM_NKG = 3;         // rows of a round are ordered by the last active stage (groups: <= median, +1, beyond),
                                    // so that a 128-row block of the GEMM stops its k-loop at ITS last active bound
 constexpr int ASM_NSCAN = ASM_NLIST + 5 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, sum and max of

@@ -682,8 +682,9 @@ struct nnmpc_qp {
   double *lb_d, *ub_d;  // [seg_max][nu] staging for host inputs
   double* in_stage;     // [seg_max][n_aug]
   hipStream_t stream;
-  hipStream_t stream2 = nullptr;     // side stream of the active-set rounds (large-set kernels)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream2 = nullptr;     // side streams of the active-set rounds (large-set kernels: the families do not wait for each other)
+  hipStream_t stream3 = nullptr, stream4 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
   bool profiling;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used;
@@ -1039,21 +1040,39 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       const int nwg32 = a.use_wg ? cnt[ASM_CNT_BIG32] : 0;
       int nbig = cnt[1] + cnt[ASM_CNT_BIG32] + nreg2_wg + nreg32b_wg + nwg64, nreg_wg = 0, nreg32_wg = 0;
       for (int b = 0; b < ASM_NREG; ++b) { nreg_wg += (cnt[4 + b] + 3) / 4; nreg32_wg += (cnt[ASM_CNT_F32 + b] + 3) / 4; }
+      // three side streams: [slab kernel: few workgroups, long chains -- it starts first and runs beside everything else],
+      // [four-wave kernels of the 12 .. 16-block sets], [single-wave kernels of the 10- and 11-block classes]
+      const bool side4 = cnt[1] > 0, side2 = nwg64 + nwg32 > 0 || (cnt[ASM_CNT_BIG32] && !a.use_wg), side3 = nreg2_wg + nreg32b_wg > 0;
       if (nbig) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        if (nwg64) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nwg64), dim3(256), asm_wg_lds_bytes<double>(), h->stream2, a);
-        if (nwg32) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nwg32), dim3(256), asm_wg_lds_bytes<float>(), h->stream2, a);
-        if (nreg2_wg) hipLaunchKernelGGL(asm_lambda_reg2_k, dim3(nreg2_wg), dim3(128), ASM_REG2_LDS, h->stream2, a);
-        if (nreg32b_wg) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3(nreg32b_wg), dim3(256), ASM_REG32B_LDS, h->stream2, a);
-        if (cnt[ASM_CNT_BIG32] && !a.use_wg) hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(cnt[ASM_CNT_BIG32], 4096)), dim3(512), ASM_TILE32_LDS, h->stream2, a);
-        if (cnt[1]) hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream2, a, 0);
-        HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+        if (side4) {
+          HIPCHK(hipStreamWaitEvent(h->stream4, h->ev_fork, 0));
+          hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream4, a, 0);
+          HIPCHK(hipEventRecord(h->ev_join4, h->stream4));
+        }
+        if (side2) {
+          HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+          if (nwg64) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nwg64), dim3(256), asm_wg_lds_bytes<double>(), h->stream2, a);
+          if (nwg32) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nwg32), dim3(256), asm_wg_lds_bytes<float>(), h->stream2, a);
+          if (cnt[ASM_CNT_BIG32] && !a.use_wg) hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(cnt[ASM_CNT_BIG32], 4096)), dim3(512), ASM_TILE32_LDS, h->stream2, a);
+          HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+        }
+        if (side3) {
+          HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
+          // fp64, 145 .. 176 bounds: two waves per problem (7.3 / 5.2 problems per microsecond at 160 / 176 bounds against the 6.0 / 4.5
+          // of the single-wave kernel; in f32 the single-wave kernel wins, 18.1 against 14.3)
+          if (nreg2_wg && a.use_wg) hipLaunchKernelGGL(asm_lambda_wg64s_k, dim3(cnt[4 + 6] + cnt[4 + 7]), dim3(128), asm_wg_lds_bytes<double>(), h->stream3, a);
+          else if (nreg2_wg) hipLaunchKernelGGL(asm_lambda_reg2_k, dim3(nreg2_wg), dim3(128), ASM_REG2_LDS, h->stream3, a);
+          if (nreg32b_wg) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3(nreg32b_wg), dim3(256), ASM_REG32B_LDS, h->stream3, a);
+          HIPCHK(hipEventRecord(h->ev_join3, h->stream3));
+        }
       }
       // fp64 first (its waves are the long ones), then the f32 rounds of the problems whose set still moves
       if (nreg_wg) { EvScope e8(h, 8, 0.0); hipLaunchKernelGGL(asm_lambda_reg_k, dim3(nreg_wg), dim3(256), ASM_REG_LDS, s, a); }
       if (nreg32_wg) { EvScope e7(h, 7, 0.0); hipLaunchKernelGGL(asm_lambda_reg32_k, dim3(nreg32_wg), dim3(256), ASM_REG32_LDS, s, a); }
-      if (nbig) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+      if (side2) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+      if (side3) HIPCHK(hipStreamWaitEvent(s, h->ev_join3, 0));
+      if (side4) HIPCHK(hipStreamWaitEvent(s, h->ev_join4, 0));
     }
     {
       // the running problems sit in rows 0..n64-1 of LAM (fp64 solves) and 0..n32-1 of LAM32 (f32 solves), the rest
@@ -1195,7 +1214,9 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->have_kunc = Kunc != nullptr;
   if ((size_t)(h->np + 5 * h->NB) * 4 > 96 * 1024) { set_error("n too large for the LDS-resident solve vector"); delete h; return NNMPC_EINVAL; }
   if (hipStreamCreate(&h->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return NNMPC_EHIP; }
-  if (hipStreamCreate(&h->stream2) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+  if (hipStreamCreate(&h->stream2) != hipSuccess || hipStreamCreate(&h->stream3) != hipSuccess || hipStreamCreate(&h->stream4) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
     set_error("hipStreamCreate / hipEventCreate failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP;
   }
@@ -1330,7 +1351,11 @@ int nnmpc_qp_destroy(nnmpc_qp* h) {
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->ev_join3) hipEventDestroy(h->ev_join3);
+  if (h->ev_join4) hipEventDestroy(h->ev_join4);
   if (h->stream2) hipStreamDestroy(h->stream2);
+  if (h->stream3) hipStreamDestroy(h->stream3);
+  if (h->stream4) hipStreamDestroy(h->stream4);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return NNMPC_OK;

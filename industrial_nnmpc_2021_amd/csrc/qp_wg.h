@@ -340,4 +340,24 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_wg64_k(AsmDev d) {
   if ((int)blockIdx.x < d.counters[ASM_CNT_BIG64]) asm_lambda_wg_any<double>(d, d.binlist[(size_t)(ASM_NLIST + 1) * d.nseg + blockIdx.x]);
 }
 
+// The 10- and 11-block classes (145 .. 176 bounds) with TWO waves per problem: the same number of problems per CU as the
+// single-wave kernels (four in f32, two in fp64), half the tiles and half the trailing update per wave.  The solver uses the
+// fp64 instance (7.3 / 5.2 problems per microsecond at 160 / 176 bounds, asm_lambda_reg2_k: 6.0 / 4.5); the f32 instance
+// loses to asm_lambda_reg32b_k (14.3 against 18.1 at 160) and is kept for scripts/micro only.
+template <class T>
+__device__ __forceinline__ void asm_lambda_wg2(const AsmDev& d, int c7, int c6) {
+  int w = blockIdx.x, list;
+  const int n1 = d.counters[c7], n0 = d.counters[c6];
+  if (w < n1) list = asm_list_of_counter(c7);
+  else if ((w -= n1) < n0) list = asm_list_of_counter(c6);
+  else return;
+  const int p = d.binlist[(size_t)list * d.nseg + w];
+  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
+  if (m <= 0 || m > 176) return;
+  if (m > 160) asm_lambda_wg<T, 11, 2>(d, p, m);
+  else asm_lambda_wg<T, 10, 2>(d, p, m);
+}
+__global__ __launch_bounds__(128, 4) void asm_lambda_wg32s_k(AsmDev d) { asm_lambda_wg2<float>(d, ASM_CNT_F32 + 7, ASM_CNT_F32 + 6); }
+__global__ __launch_bounds__(128, 2) void asm_lambda_wg64s_k(AsmDev d) { asm_lambda_wg2<double>(d, 4 + 7, 4 + 6); }
+
 }  // namespace nnmpc

@@ -92,7 +92,9 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
-    if (variant == 5) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<float>(), 0, d);
+    if (variant == 7) hipLaunchKernelGGL(asm_lambda_wg32s_k, dim3(nseg), dim3(128), asm_wg_lds_bytes<float>(), 0, d);
+    else if (variant == 8) hipLaunchKernelGGL(asm_lambda_wg64s_k, dim3(nseg), dim3(128), asm_wg_lds_bytes<double>(), 0, d);
+    else if (variant == 5) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<float>(), 0, d);
     else if (variant == 6) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<double>(), 0, d);
     else if (variant == 4) {                                  // f32 LDS-tile workgroup kernel (177..256 bounds)
       static bool once4 = false;
@@ -126,7 +128,7 @@ int main(int argc, char** argv) {
   double worst = 0.0;
   for (int pp = 0; pp < 2; ++pp) {
     const int p = pp == 0 ? 0 : nseg - 1;
-    if (variant == 2 || variant == 3 || variant == 4 || variant == 5) {
+    if (variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7) {
       std::vector<float> l32(np);
       CK(hipMemcpy(l32.data(), dlam32 + (size_t)p * np, np * 4, hipMemcpyDeviceToHost));
       for (int i = 0; i < np; ++i) lam[i] = l32[i];
