@@ -118,6 +118,7 @@ struct AsmDev {
   const double* xhw;               // [rows] = lamw * H, all columns
   int* wlist;                      // [ASM_NKG][wcap] those problems by k-group; their numbers are counters[ASM_CNT_WIDEG + g]
   int wcap;                        // rows per region of lamw / xhw / wlist
+  int tail_gi;                     // asm_tail_k: dual active-set steps (Goldfarb-Idnani) instead of Murty's single exchanges once block exchanges stop making progress (off: measured slower, see there)
   int use_wg;                      // sets of 145 .. 256 bounds go to the four-wave register kernels (qp_wg.h); 0: the single-wave / LDS-tile / slab kernels (A/B)
   int early64;                     // an f32 round that moves at most this many bounds is followed by an fp64 round (0: only a settled set is)
   int* wflag;                      // [nseg] set by asm_wide_gemm_k when a bound beyond the window is violated (cleared by asm_wide_k)
@@ -1442,29 +1443,75 @@ constexpr int ASM_FM = 160;
 constexpr int ASM_TAIL_GRACE = 2;
 constexpr int ASM_TAIL_AREA = ASM_FM * (ASM_FM + 3) / 2 > ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS
                                   ? ASM_FM * (ASM_FM + 3) / 2 : ASM_TAIL_MB * (ASM_TAIL_MB + 1) / 2 * ASM_TS;   // doubles: tiles or factor
-constexpr int ASM_TAIL_EXTRA = ASM_FM * (4 + 8 + 8);      // al, rhs, work vector
+constexpr int ASM_TAIL_EXTRA = ASM_FM * (4 + 8 + 8 + 8);  // al, rhs, two work vectors
 __device__ __forceinline__ int asm_frow(int i) { return i * (i + 3) / 2; }
 
-// v <- L^-1 v  (v[0..m) in LDS)
+// v <- L^-1 v  (v[0..m) in LDS, m < ASM_FM <= 192).  The vector lives in three registers per lane (element lane + 64 u), the
+// pivot element goes round by v_readlane, the reciprocals of the diagonal are formed once, in parallel: one LDS read and two
+// FMAs per lane in the dependent chain of a step.  (The first version kept v in LDS -- four LDS round trips and an fp64
+// division per step: 20 us per substitution at 100 bounds, two or three substitutions per iteration of asm_tail_k.)
+static_assert(ASM_FM <= 192, "asm_fwd / asm_bwd hold the vector in three registers per lane");
 __device__ __forceinline__ void asm_fwd(const double* Ld, double* v, int m, int lane) {
-  for (int k = 0; k < m; ++k) {
-    const double yk = v[k] / Ld[asm_frow(k) + k];
-    ASM_FENCE();
-    if (lane == 0) v[k] = yk;
-    for (int i = k + 1 + lane; i < m; i += 64) v[i] -= Ld[asm_frow(i) + k] * yk;
-    ASM_FENCE();
+  double x[3], idg[3], ln[3];
+  const double* rowp[3];                                     // row of element lane + 64 u (clamped to the last row: reads stay inside L)
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int i = lane + 64 * u, ic = min(i, m - 1);
+    rowp[u] = Ld + asm_frow(ic);
+    x[u] = i < m ? v[i] : 0.0;
+    idg[u] = i < m ? 1.0 / rowp[u][i] : 0.0;
+    ln[u] = rowp[u][0];
   }
+  // branch-free steps, the three LDS reads of step k + 1 issued before the arithmetic of step k (entries at or above the
+  // diagonal are read and not used)
+  for (int k = 0; k < m; ++k) {
+    const int ku = k >> 6, kl = k & 63;
+    double lc[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { lc[u] = ln[u]; ln[u] = rowp[u][min(k + 1, m - 1)]; }
+    const double t = (ku == 0 ? x[0] * idg[0] : (ku == 1 ? x[1] * idg[1] : x[2] * idg[2]));
+    const double yk = rdlane_d(t, kl);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = lane + 64 * u;
+      const double upd = x[u] - lc[u] * yk;
+      x[u] = i == k ? yk : ((i > k && i < m) ? upd : x[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { const int i = lane + 64 * u; if (i < m) v[i] = x[u]; }
+  ASM_FENCE();
 }
 // v <- L^-T v
 __device__ __forceinline__ void asm_bwd(const double* Ld, double* v, int m, int lane) {
-  for (int k = m - 1; k >= 0; --k) {
-    const double* row = Ld + asm_frow(k);
-    const double lk = v[k] / row[k];
-    ASM_FENCE();
-    if (lane == 0) v[k] = lk;
-    for (int i = lane; i < k; i += 64) v[i] -= row[i] * lk;
-    ASM_FENCE();
+  double x[3], idg[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int i = lane + 64 * u;
+    x[u] = i < m ? v[i] : 0.0;
+    idg[u] = i < m ? 1.0 / Ld[asm_frow(i) + i] : 0.0;
   }
+  double ln[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) ln[u] = m > 0 ? Ld[asm_frow(m - 1) + min(lane + 64 * u, m - 1)] : 0.0;
+  for (int k = m - 1; k >= 0; --k) {
+    const int ku = k >> 6, kl = k & 63;
+    double lc[3];
+    const double* rown = Ld + asm_frow(max(k - 1, 0));       // row k - 1 for the next step: columns 0..k-1 (k is its spare slot)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { lc[u] = ln[u]; ln[u] = rown[min(lane + 64 * u, max(k - 1, 0))]; }
+    const double t = (ku == 0 ? x[0] * idg[0] : (ku == 1 ? x[1] * idg[1] : x[2] * idg[2]));
+    const double lk = rdlane_d(t, kl);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = lane + 64 * u;
+      const double upd = x[u] - lc[u] * lk;
+      x[u] = i == k ? lk : (i < k ? upd : x[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { const int i = lane + 64 * u; if (i < m) v[i] = x[u]; }
+  ASM_FENCE();
 }
 
 __global__ __launch_bounds__(256) void asm_taillist_k(AsmDev d) {
@@ -1477,9 +1524,15 @@ __global__ __launch_bounds__(256) void asm_taillist_k(AsmDev d) {
 // (one forward substitution) or drops one (Givens rotations over the trailing columns) instead of gathering and
 // factoring |A|^2 entries again; multipliers by two substitutions.  Every accepted result still passes the fp64
 // certificate, so a factor that lost accuracy can only cost time (the problem then falls back to the PDIP path).
+#ifdef ASM_TAIL_PROF
+__device__ unsigned long long asm_tail_prof[8];            // diagnostics build only: shader-clock sums per phase over all workgroups
+#define ASM_TP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(&asm_tail_prof[i], t_ - tp_); tp_ = t_; } while (0)
+#else
+#define ASM_TP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ int s_bad, wsum[4], s_i[4], s_m, s_fast;
+  __shared__ int s_bad, wsum[4], s_i[4], s_n[4], s_m, s_fast;
   __shared__ double s_d[12];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= d.counters[ASM_CNT_TAIL]) return;
@@ -1491,7 +1544,8 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   unsigned char* dec = reinterpret_cast<unsigned char*>(Tl + ASM_TAIL_AREA);   // [n] decisions
   double* rhs = reinterpret_cast<double*>(dec + ((d.n + 15) / 16) * 16);   // [ASM_FM] x_unc,A - b_A in factor order
   double* vv = rhs + ASM_FM;                                 // [ASM_FM] work vector
-  int* al = reinterpret_cast<int*>(vv + ASM_FM);             // [ASM_FM] active indices in factor order
+  double* ww = vv + ASM_FM;                                  // [ASM_FM] second work vector (dual steps)
+  int* al = reinterpret_cast<int*>(ww + ASM_FM);             // [ASM_FM] active indices in factor order
   double* Tg = d.scratch + (size_t)blockIdx.x * ((size_t)(d.max_active / 16) * (d.max_active / 16 + 1) / 2 * ASM_TS);
   const size_t o = (size_t)p * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
@@ -1501,11 +1555,59 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   int best = d.ninf_best[p], grace = d.alpha[p], hi = d.hi[p], rounds = d.rounds[p];
   int single = 0;                                            // the previous iteration ended with a single exchange
   int fast = 0, m = 0;                                       // dense factor valid for the current set (of size m)
+  int gi = 0;                                                // dual active-set phase (see the exchange rule below)
+  // one row leaves the dense factor (wave 0): the logical arrays and the rows of L move up, Givens rotations restore the triangle
+  auto drop_row = [&](int j, int mm) {
+    int av[3]; double hv[3], lv[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = j + lane + 64 * u;
+      av[u] = 0; hv[u] = 0.0; lv[u] = 0.0;
+      if (i + 1 < mm) { av[u] = al[i + 1]; hv[u] = rhs[i + 1]; lv[u] = rA[i + 1]; }
+    }
+    ASM_FENCE();
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = j + lane + 64 * u;
+      if (i + 1 < mm) { al[i] = av[u]; rhs[i] = hv[u]; rA[i] = lv[u]; }
+    }
+    // new row i = old row i + 1 (columns 0..i + 1), in ascending order
+    for (int i = j; i + 1 < mm; ++i) {
+      const double* src = Ld + asm_frow(i + 1);
+      double* dst = Ld + asm_frow(i);
+      double tv[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { const int c = lane + 64 * u; tv[u] = c <= i + 1 ? src[c] : 0.0; }
+      ASM_FENCE();
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { const int c = lane + 64 * u; if (c <= i + 1) dst[c] = tv[u]; }
+      ASM_FENCE();
+    }
+    --mm;
+    for (int k = j; k < mm; ++k) {                           // row i >= j now has an entry in column i + 1
+      double* rk = Ld + asm_frow(k);
+      const double a = rk[k], b = rk[k + 1];
+      const double rr = sqrt(a * a + b * b), c = a / rr, s = b / rr;
+      ASM_FENCE();
+      if (lane == 0) { rk[k] = rr; rk[k + 1] = 0.0; }
+      for (int i = k + 1 + lane; i < mm; i += 64) {
+        double* ri = Ld + asm_frow(i);
+        const double pp = ri[k], qq = ri[k + 1];
+        ri[k] = c * pp + s * qq;
+        ri[k + 1] = c * qq - s * pp;
+      }
+      ASM_FENCE();
+    }
+  };
+#ifdef ASM_TAIL_PROF
+  unsigned long long tp_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int it = 0; it < budget; ++it) {
+    ASM_TP(4);
     if (!fast) {
       m = asm_count_one(d, p, hi, wsum);
       if (m > d.max_active) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
-      if (single && m > 0 && m < ASM_FM) {
+      if (single && (m > 0 || gi) && m < ASM_FM) {
         // ---- build the dense factor: gather the lower triangle, right-looking Cholesky (three barriers per column)
         __syncthreads();                                       // idx (asm_count_one) complete
         for (int i = tid; i < m; i += 256) {
@@ -1540,6 +1642,7 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
         if (asm_tile_solve(d, p, m, idx, rA, Yt, m <= 16 * ASM_TAIL_MB ? Tl : Tg, &s_bad)) { if (tid == 0) d.state[p] = ASM_FALLBACK; return; }
       }
     }
+    ASM_TP(0);
     if (fast) {                                              // lam = L^-T L^-1 rhs  (wave 0)
       if (wave == 0) {
         for (int i = lane; i < m; i += 64) vv[i] = rhs[i];
@@ -1550,9 +1653,11 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       }
       __syncthreads();
     }
+    ASM_TP(1);
     const int* lst = fast ? al : idx;                        // the set the multipliers rA[0..m) belong to
     // x and the tests, decisions recorded (255: stays)
     int ninf = 0, rmin = 0x7fffffff;                         // rmin: the infeasible index a single exchange takes (the smallest)
+    int nneg = 0;                                            // active bounds whose multiplier has the wrong sign
     double l1 = 0.0, lmin = 1e300;
     for (int r = tid; r < d.n; r += 256) {
       const int sr = st[r];
@@ -1566,6 +1671,17 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
         const double* Hc = d.H + r;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int i = 0;
+        // sixteen loads in flight per thread (the entries come from L2 / Infinity Cache at ~1 us each: four at a time made this
+        // loop -- m / 4 dependent round trips per 256 columns -- most of an iteration)
+        for (; i + 16 <= m; i += 16) {
+          double h[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) h[u] = Hc[(size_t)lst[i + u] * d.np];
+#pragma unroll
+          for (int u = 0; u < 16; u += 4) {
+            a0 += h[u] * rA[i + u]; a1 += h[u + 1] * rA[i + u + 1]; a2 += h[u + 2] * rA[i + u + 2]; a3 += h[u + 3] * rA[i + u + 3];
+          }
+        }
         for (; i + 4 <= m; i += 4) {
           a0 += Hc[(size_t)lst[i] * d.np] * rA[i];
           a1 += Hc[(size_t)lst[i + 1] * d.np] * rA[i + 1];
@@ -1582,22 +1698,28 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       if (dc != 255) { ++ninf; rmin = min(rmin, r); }
     }
     __syncthreads();                                         // dec of the free variables complete
+    ASM_TP(2);
     for (int i = tid; i < m; i += 256) {
       const int a = lst[i], sa = st[a];
       const double l = rA[i];
       l1 += fabs(l); lmin = fmin(lmin, fabs(l));
-      if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { dec[a] = 0; ++ninf; rmin = min(rmin, a); }
+      if ((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0)) { dec[a] = 0; ++ninf; ++nneg; if (!gi) rmin = min(rmin, a); }
     }
     for (int off = 32; off > 0; off >>= 1) {
-      ninf += __shfl_xor(ninf, off); rmin = min(rmin, __shfl_xor(rmin, off));
+      ninf += __shfl_xor(ninf, off); rmin = min(rmin, __shfl_xor(rmin, off)); nneg += __shfl_xor(nneg, off);
       l1 += __shfl_xor(l1, off); lmin = fmin(lmin, __shfl_xor(lmin, off));
     }
     __syncthreads();
-    if (lane == 0) { wsum[wave] = ninf; s_i[wave] = rmin; s_d[wave] = l1; s_d[4 + wave] = lmin; }
+    if (lane == 0) { wsum[wave] = ninf; s_i[wave] = rmin; s_n[wave] = nneg; s_d[wave] = l1; s_d[4 + wave] = lmin; }
     __syncthreads();
     ninf = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    rmin = min(min(s_i[0], s_i[1]), min(s_i[2], s_i[3]));
+    nneg = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+    rmin = min(min(s_i[0], s_i[1]), min(s_i[2], s_i[3]));           // (dual phase: the smallest VIOLATED index)
     ++rounds;
+    ASM_TP(3);
+#ifdef ASM_TAIL_PROF
+    if (tid == 0) atomicAdd(&asm_tail_prof[fast ? 5 : 6], 1ull);
+#endif
     if (ninf == 0 && fast) {                                 // settled on an updated factor: confirm with a fresh
       fast = 0; single = 0;                                  // factorisation of the same set (next iteration)
       __syncthreads();
@@ -1625,11 +1747,101 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
     single = 0;
     // (the problems that reach the tail have shown that block exchanges do not settle them: a new minimum buys
     // ASM_TAIL_GRACE block exchanges here, not ASM_GRACE, so most iterations are cheap single exchanges)
-    if (ninf < best) { best = ninf; grace = ASM_TAIL_GRACE; }
+    if (gi) single = 1;
+    else if (ninf < best) { best = ninf; grace = ASM_TAIL_GRACE; }
     else if (grace > 0) --grace;
     else single = 1;
-    const int dsel = dec[rmin];                              // what the single exchange does: 1 / 2 add at that bound, 0 drop
+    if (single && !gi && d.tail_gi && m + 1 < ASM_FM) {
+      // (NNMPC_TAIL_GI=1 only; OFF by default.)  From here on: DUAL active-set steps (Goldfarb & Idnani 1983) instead of Murty's
+      // one-index-per-iteration rule.  Measured: no better -- the stragglers of the cond-4e7 plant need the same number of
+      // iterations either way (36 at most in a 10 000-problem batch), a dual iteration costs more (the purge refactors, every
+      // step takes two more substitutions): 5.8 against 5.2 ms per CSTRs-size step; on random dense Hessians with cond >= 1e5
+      // and half the bounds active (scripts/stress_asm.py, seeds 1 and 3) it exhausts the iteration budget MORE often (174 and
+      // 308 of ~1600 problems against 130 and 166): after the purge it has to add the missing bounds one by one.  Kept for A/B.
+      // (i) Purge: drop ALL bounds with a wrong-sign multiplier, solve again, until the set is
+      // dual feasible -- x is then the optimum on that set with multipliers >= 0.  (ii) Add the violated bound with the smallest
+      // index by a dual step: multipliers of the set move along -w, w = S^-1 H[A,r] (two substitutions with the dense factor);
+      // a bound whose multiplier reaches zero first leaves (Givens downdate) and the step is repeated, else the new bound
+      // joins (append a row).  Every step raises the dual objective: no cycling, and the number of steps is about the number of
+      // bounds still missing.  Multipliers and x are recomputed from the factor after every completed step; a set that settles
+      // is confirmed by a fresh factorisation and the certificate like any other.
+      gi = 1;
+    }
+    if (gi && m + 1 >= ASM_FM) gi = 0;                       // too large for the dense factor: Murty's rule on fresh factorisations
+    const int dsel = dec[rmin < d.n ? rmin : 0];             // what the single exchange does: 1 / 2 add at that bound, 0 drop
     __syncthreads();
+    if (gi) {
+      hi = d.n;
+      if (nneg > 0 || !fast) {
+        // (i) purge -- or, dual feasible already, nothing: the next iteration builds the dense factor of the set as it stands
+        for (int r = tid; r < d.n; r += 256) if (dec[r] == 0) st[r] = 0;
+        fast = 0;
+        __syncthreads();
+        continue;
+      }
+      // (ii) dual step for bound rmin (violated; the set is dual feasible, the dense factor valid), wave 0
+      if (wave == 0) {
+        int ok = 1, mm = m;
+        const int r = rmin, sp = dsel == 1 ? 1 : -1;
+        const double bp = dsel == 1 ? ubp[r % d.nu] : lbp[r % d.nu];
+        double viol = sp * (d.x[o + r] - bp), mup = 0.0;     // > bound_tol
+        const double* Hr = d.H + (size_t)r * d.np;
+        const double hd = Hr[r];
+        int done = 0;
+        for (int step = 0; step < ASM_FM + 8 && ok && !done; ++step) {
+          for (int i = lane; i < mm; i += 64) vv[i] = Hr[al[i]];
+          ASM_FENCE();
+          asm_fwd(Ld, vv, mm, lane);
+          double s2 = 0.0;
+          for (int i = lane; i < mm; i += 64) s2 += vv[i] * vv[i];
+          for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+          const double d2 = hd - s2;                         // n_p' (H - H[:,A] S^-1 H[A,:]) n_p > 0
+          if (!(d2 > 1e-13 * hd)) { ok = 0; break; }
+          for (int i = lane; i < mm; i += 64) ww[i] = vv[i];
+          ASM_FENCE();
+          asm_bwd(Ld, ww, mm, lane);                         // w = S^-1 H[A,r]
+          // largest step that keeps every multiplier of the set >= 0:  mu_j = s_j lam_j falls by t s_j s_p w_j
+          double t1 = 1e300; int k1 = -1;
+          for (int i = lane; i < mm; i += 64) {
+            const int sj = st[al[i]] == 1 ? 1 : -1;
+            const double rj = sj * sp * ww[i];
+            if (rj > 0.0) { const double q = fmax(sj * rA[i], 0.0) / rj; if (q < t1) { t1 = q; k1 = i; } }
+          }
+          for (int off = 32; off > 0; off >>= 1) {
+            const double t_o = __shfl_xor(t1, off); const int k_o = __shfl_xor(k1, off);
+            if (t_o < t1 || (t_o == t1 && k_o >= 0 && (k1 < 0 || k_o < k1))) { t1 = t_o; k1 = k_o; }
+          }
+          const double t2 = viol / d2;                       // full step: the new bound becomes active
+          const double t = t2 <= t1 ? t2 : t1;
+          for (int i = lane; i < mm; i += 64) rA[i] -= t * sp * ww[i];
+          mup += t;
+          ASM_FENCE();
+          if (t2 <= t1) {
+            if (mm + 1 >= ASM_FM) { ok = 0; break; }
+            double* row = Ld + asm_frow(mm);
+            for (int i = lane; i < mm; i += 64) row[i] = vv[i];
+            if (lane == 0) {
+              row[mm] = sqrt(d2); al[mm] = r; rhs[mm] = d.xunc[o + r] - bp; rA[mm] = sp * mup;
+              st[r] = (unsigned char)dsel;
+            }
+            ASM_FENCE();
+            ++mm; done = 1;
+          } else {
+            viol -= t * d2;
+            if (lane == 0) st[al[k1]] = 0;
+            ASM_FENCE();
+            drop_row(k1, mm);
+            --mm;
+          }
+        }
+        if (!done) ok = 0;
+        if (lane == 0) { s_m = mm; s_fast = ok; }
+      }
+      __syncthreads();
+      m = s_m; fast = s_fast;
+      __syncthreads();
+      continue;
+    }
     for (int r = tid; r < d.n; r += 256) {
       const unsigned char dc = dec[r];
       if (dc != 255 && (!single || r == rmin)) st[r] = dc;
@@ -1668,47 +1880,8 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
           for (int off = 32; off > 0; off >>= 1) j = max(j, __shfl_xor(j, off));
           if (j < 0) ok = 0;
           else {
-            // shift the logical arrays (three elements per lane at most: read, then write) ...
-            int av[3]; double hv[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int i = j + lane + 64 * u;
-              av[u] = 0; hv[u] = 0.0;
-              if (i + 1 < mm) { av[u] = al[i + 1]; hv[u] = rhs[i + 1]; }
-            }
-            ASM_FENCE();
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int i = j + lane + 64 * u;
-              if (i + 1 < mm) { al[i] = av[u]; rhs[i] = hv[u]; }
-            }
-            // ... and the rows of the factor: new row i = old row i + 1 (columns 0..i + 1), in ascending order
-            for (int i = j; i + 1 < mm; ++i) {
-              const double* src = Ld + asm_frow(i + 1);
-              double* dst = Ld + asm_frow(i);
-              double tv[3];
-#pragma unroll
-              for (int u = 0; u < 3; ++u) { const int c = lane + 64 * u; tv[u] = c <= i + 1 ? src[c] : 0.0; }
-              ASM_FENCE();
-#pragma unroll
-              for (int u = 0; u < 3; ++u) { const int c = lane + 64 * u; if (c <= i + 1) dst[c] = tv[u]; }
-              ASM_FENCE();
-            }
+            drop_row(j, mm);
             --mm;
-            for (int k = j; k < mm; ++k) {                     // row i >= j now has an entry in column i + 1
-              double* rk = Ld + asm_frow(k);
-              const double a = rk[k], b = rk[k + 1];
-              const double rr = sqrt(a * a + b * b), c = a / rr, s = b / rr;
-              ASM_FENCE();
-              if (lane == 0) { rk[k] = rr; rk[k + 1] = 0.0; }
-              for (int i = k + 1 + lane; i < mm; i += 64) {
-                double* ri = Ld + asm_frow(i);
-                const double pp = ri[k], qq = ri[k + 1];
-                ri[k] = c * pp + s * qq;
-                ri[k + 1] = c * qq - s * pp;
-              }
-              ASM_FENCE();
-            }
           }
         }
         if (lane == 0) { s_m = mm; s_fast = ok; }

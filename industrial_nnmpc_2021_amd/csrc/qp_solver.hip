@@ -932,6 +932,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wflag = h->asm_wflag; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.ldu = h->ldu; a.nout = h->nout; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
+  { static const int tgi = getenv("NNMPC_TAIL_GI") ? 1 : 0; a.tail_gi = tgi; }   // (the variable: diagnostics, A/B of the tail's exchange rule)
   { static const int wg = getenv("NNMPC_NO_WG") ? 0 : 1; a.use_wg = wg; }   // (the variable: diagnostics, A/B against the kernels it replaced)
   { static const int e64 = getenv("NNMPC_EARLY64") ? atoi(getenv("NNMPC_EARLY64")) : 4; a.early64 = e64; }   // (the variable: diagnostics, A/B of the rule)
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
@@ -1020,6 +1021,24 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       hipLaunchKernelGGL(asm_tail_k, dim3(nrun), dim3(256), lds_tail, s, a, a.max_rounds);
       HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(stream_sync(s));
+      {
+        static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations of the tail's problems
+        if (trace) {
+          std::vector<int> rd(nprob), bl(nrun);
+          hipMemcpy(rd.data(), h->asm_rounds, nprob * sizeof(int), hipMemcpyDeviceToHost);
+          hipMemcpy(bl.data(), h->asm_biglist, nrun * sizeof(int), hipMemcpyDeviceToHost);
+          long sum = 0; int mx = 0;
+          for (int i = 0; i < nrun; ++i) { const int r = rd[bl[i]] - rounds; sum += r; mx = std::max(mx, r); }
+          fprintf(stderr, "asm tail after round %d: %d problems, iterations mean %.1f max %d\n", rounds, nrun, (double)sum / nrun, mx);
+#ifdef ASM_TAIL_PROF
+          unsigned long long tp[8];
+          hipMemcpyFromSymbol(tp, HIP_SYMBOL(asm_tail_prof), sizeof tp);
+          fprintf(stderr, "  tail clock sums (all workgroups): count/factor/solve %llu, substitutions %llu, x loop %llu, tests %llu, exchange %llu; iterations on the dense factor %llu, on a fresh factorisation %llu\n",
+                  tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6]);
+          memset(tp, 0, sizeof tp); hipMemcpyToSymbol(HIP_SYMBOL(asm_tail_prof), tp, sizeof tp);
+#endif
+        }
+      }
       h->stats.asm_rounds += 1;
       rounds = 0;                                         // (regular exit: the counters just read are final)
       break;
