@@ -1659,7 +1659,17 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
     int ninf = 0, rmin = 0x7fffffff;                         // rmin: the infeasible index a single exchange takes (the smallest)
     int nneg = 0;                                            // active bounds whose multiplier has the wrong sign
     double l1 = 0.0, lmin = 1e300;
-    for (int r = tid; r < d.n; r += 256) {
+    // Column window, as in the lock-step rounds: while the set is still moving only the columns up to one stage past the last
+    // active bound are evaluated (in MPC the active bounds sit in the first stages: 512 of 4480 columns at CDU size -- the x loop
+    // over ALL columns was most of an iteration); a set that settles inside the window gets the remaining columns once, and a
+    // bound violated out there sends the problem on.  (On the dense factor -- single exchanges -- the list is not ordered: all
+    // columns.)
+    const int lastact = m > 0 ? idx[m - 1] : -1;
+    const int xlim = fast ? d.n : min(d.n, ((lastact + 1 + d.nu + 255) / 256) * 256);
+    int xdone = xlim;                                        // columns whose decisions dec[] are this iteration's
+    // x over the columns [r0, r1) and the feasibility tests of the free variables there
+    auto xpass = [&](int r0, int r1, int& ninf, int& rmin) {
+    for (int r = r0 + tid; r < r1; r += 256) {
       const int sr = st[r];
       const int k = r % d.nu;
       const double lb = lbp[k], ub = ubp[k];
@@ -1697,6 +1707,8 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       dec[r] = dc;
       if (dc != 255) { ++ninf; rmin = min(rmin, r); }
     }
+    };
+    xpass(0, xlim, ninf, rmin);
     __syncthreads();                                         // dec of the free variables complete
     ASM_TP(2);
     for (int i = tid; i < m; i += 256) {
@@ -1715,6 +1727,17 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
     ninf = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     nneg = s_n[0] + s_n[1] + s_n[2] + s_n[3];
     rmin = min(min(s_i[0], s_i[1]), min(s_i[2], s_i[3]));           // (dual phase: the smallest VIOLATED index)
+    if (ninf == 0 && xlim < d.n) {                           // settled inside the window: the columns beyond, once
+      int ninf2 = 0, rmin2 = 0x7fffffff;
+      xpass(xlim, d.n, ninf2, rmin2);
+      for (int off = 32; off > 0; off >>= 1) { ninf2 += __shfl_xor(ninf2, off); rmin2 = min(rmin2, __shfl_xor(rmin2, off)); }
+      __syncthreads();
+      if (lane == 0) { wsum[wave] = ninf2; s_i[wave] = rmin2; }
+      __syncthreads();
+      ninf = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      rmin = min(min(s_i[0], s_i[1]), min(s_i[2], s_i[3]));
+      xdone = d.n;
+    }
     ++rounds;
     ASM_TP(3);
 #ifdef ASM_TAIL_PROF
@@ -1774,7 +1797,7 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       hi = d.n;
       if (nneg > 0 || !fast) {
         // (i) purge -- or, dual feasible already, nothing: the next iteration builds the dense factor of the set as it stands
-        for (int r = tid; r < d.n; r += 256) if (dec[r] == 0) st[r] = 0;
+        for (int r = tid; r < xdone; r += 256) if (dec[r] == 0) st[r] = 0;
         fast = 0;
         __syncthreads();
         continue;
@@ -1842,7 +1865,7 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
       __syncthreads();
       continue;
     }
-    for (int r = tid; r < d.n; r += 256) {
+    for (int r = tid; r < xdone; r += 256) {
       const unsigned char dc = dec[r];
       if (dc != 255 && (!single || r == rmin)) st[r] = dc;
     }

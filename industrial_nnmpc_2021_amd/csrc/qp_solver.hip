@@ -956,6 +956,15 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(stream_sync(s));
     h->stats.asm_rounds += 1;
+    static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations per problem
+    if (trace) {
+      std::vector<int> rd(nprob), mg(nprob);
+      hipMemcpy(rd.data(), h->asm_rounds, nprob * sizeof(int), hipMemcpyDeviceToHost);
+      hipMemcpy(mg.data(), h->asm_mg, nprob * sizeof(int), hipMemcpyDeviceToHost);
+      long sum = 0, sm = 0; int mx = 0, mm = 0;
+      for (int i = 0; i < nprob; ++i) { sum += rd[i]; mx = std::max(mx, rd[i]); sm += mg[i]; mm = std::max(mm, mg[i]); }
+      fprintf(stderr, "asm tail only: %d problems, iterations mean %.2f max %d, active bounds mean %.1f max %d\n", nprob, (double)sum / nprob, mx, (double)sm / nprob, mm);
+    }
   }
   for (; !tail_only && rounds < 2 * a.max_rounds + 2; ++rounds) {
     if (prev_run) {
