@@ -684,6 +684,7 @@ struct nnmpc_qp {
   hipStream_t stream;
   hipStream_t stream2 = nullptr;     // side streams of the active-set rounds (large-set kernels: the families do not wait for each other)
   hipStream_t stream3 = nullptr, stream4 = nullptr;
+  int asm_tail_budget = 4000;        // iterations of asm_tail_k per problem
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
   bool profiling;
   std::vector<hipEvent_t> ev_pool;
@@ -952,7 +953,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     EvScope es(h, 4, 0.0);
     hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
     const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_AREA) * 8 + ((h->n + 15) / 16) * 16 + ASM_TAIL_EXTRA;
-    hipLaunchKernelGGL(asm_tail_k, dim3(nprob), dim3(256), lds_tail, s, a, a.max_rounds);
+    hipLaunchKernelGGL(asm_tail_k, dim3(nprob), dim3(256), lds_tail, s, a, h->asm_tail_budget);
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(stream_sync(s));
     h->stats.asm_rounds += 1;
@@ -1027,7 +1028,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       EvScope es(h, 4, 0.0);
       hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
       const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_AREA) * 8 + ((h->n + 15) / 16) * 16 + ASM_TAIL_EXTRA;
-      hipLaunchKernelGGL(asm_tail_k, dim3(nrun), dim3(256), lds_tail, s, a, a.max_rounds);
+      hipLaunchKernelGGL(asm_tail_k, dim3(nrun), dim3(256), lds_tail, s, a, h->asm_tail_budget);
       HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(stream_sync(s));
       {
@@ -1225,6 +1226,10 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.asm_max_active <= 0) o.asm_max_active = 768;
   if (o.asm_max_active > 768) o.asm_max_active = 768;
   o.asm_max_active = std::max(16, (o.asm_max_active / 16) * 16);
+  // the device tail (asm_tail_k) gets 4000 iterations unless the caller set a budget: Murty's rule is finite but slow on dense
+  // Hessians with cond >= 1e5 and half the bounds active -- scripts/stress_asm.py seed 3: 166 of 1567 problems unfinished after
+  // 200 iterations, 59 after 1000, 1 after 4000, at +10 % run time; the reference's own problems settle within 40
+  h->asm_tail_budget = o.asm_max_rounds <= 0 ? 4000 : o.asm_max_rounds;
   if (o.asm_max_rounds <= 0) o.asm_max_rounds = 200;
   if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
