@@ -321,8 +321,12 @@ __device__ __forceinline__ void asm_lambda_wg_any(const AsmDev& d, int p) {
     case 14: asm_lambda_wg<T, 14, 4>(d, p, m); break;
     case 13: asm_lambda_wg<T, 13, 4>(d, p, m); break;
     case 12: asm_lambda_wg<T, 12, 4>(d, p, m); break;
+#ifdef ASM_WG_MICRO                                        // (scripts/micro only: the solver's lists hold sets of 177 .. 256 bounds)
     case 11: asm_lambda_wg<T, 11, 4>(d, p, m); break;
     default: asm_lambda_wg<T, 10, 4>(d, p, m); break;
+#else
+    default: if (threadIdx.x == 0) d.state[p] = ASM_FALLBACK; break;   // not reachable through asm_scan_col; the PDIP path if it ever is
+#endif
   }
 }
 
@@ -357,7 +361,9 @@ __device__ __forceinline__ void asm_lambda_wg2(const AsmDev& d, int c7, int c6) 
   if (m > 160) asm_lambda_wg<T, 11, 2>(d, p, m);
   else asm_lambda_wg<T, 10, 2>(d, p, m);
 }
+#ifdef ASM_WG_MICRO
 __global__ __launch_bounds__(128, 4) void asm_lambda_wg32s_k(AsmDev d) { asm_lambda_wg2<float>(d, ASM_CNT_F32 + 7, ASM_CNT_F32 + 6); }
+#endif
 __global__ __launch_bounds__(128, 2) void asm_lambda_wg64s_k(AsmDev d) { asm_lambda_wg2<double>(d, 4 + 7, 4 + 6); }
 
 }  // namespace nnmpc
