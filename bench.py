@@ -581,9 +581,9 @@ def bench_nn(ctx, B, steps, warmup):
     k = min(B, 4096)
     rows = np.concatenate(([0], np.sort(np.random.default_rng(9).choice(B, k - 1, replace=False)))) if B > k else np.arange(B)
     ref = onn.control_input(W, x_h[rows], None, xs_h[rows], us_h[rows], xscale, -np.ones(nu), np.ones(nu), False)
-    for mode in ("f32", "bf16"):
+    for mode in ("f32", "bf16", "bf16x3"):
         net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu),
-                           max_batch=262144, use_bf16=(mode == "bf16"))
+                           max_batch=262144, use_bf16={"f32": False, "bf16": True, "bf16x3": "split"}[mode])
         # 6 extra untimed forwards before the W warmup steps: on every box tried, ONE forward of the first ~100 ms of
         # sustained MFMA load starts ~40 ms late (device time of that call unchanged: the stream just starts later),
         # then none for the rest of the run; with K of a few steps that one stall would be a third of the timed region
@@ -608,7 +608,7 @@ def bench_nn(ctx, B, steps, warmup):
         net.close()
     for a in (x, xs, us, u):
         a.free()
-    f, h = res["f32"], res["bf16"]
+    f, h, s3 = res["f32"], res["bf16"], res["bf16x3"]
     traffic, tnote = pmc_traffic(f"nn_b{B}")
     rows2 = 2 * min(B, 262144)
     kavg = (((dims[0] + 63) // 64) * 64 + 2 * hid) / 3.0
@@ -633,7 +633,14 @@ def bench_nn(ctx, B, steps, warmup):
                                   "launches": h["hidden_launches"], "avg_launch_ms": h["hidden_avg_launch_ms"],
                                   "algorithmic_flops": "2 passes x 2 x (d_in h + 2 h^2) per state over the three hidden-layer launches "
                                                        "(gemm_TFLOPs: all four GEMMs incl. the HBM-bound head)",
-                                  "algorithmic_bytes_per_launch": rows2 * (kavg + hid) * 2})}
+                                  "algorithmic_bytes_per_launch": rows2 * (kavg + hid) * 2}),
+           # split bf16 (use_bf16 = 2): activations and weights as bf16 pairs hi + lo, one bf16 GEMM of three times the depth per
+           # layer; ALGORITHMIC flops (those of the f32 path) over its time -- the matrix pipes do three times as many
+           "bf16x3": dict(s3, tolerance=1e-4,
+                          note="f32-grade results from the bf16 matrix pipes: hi hi' + hi lo' + lo hi' per layer (gemm_nt_bf16_wide_k, "
+                               "K three times as deep); hidden_TFLOPs counts the algorithmic flops, the pipes execute 3 x that",
+                          executed_hidden_TFLOPs=3.0 * s3["hidden_TFLOPs"], frac_of_bf16_peak_executed=3.0 * s3["hidden_TFLOPs"] / BF16_PEAK_TFLOPS,
+                          speedup_over_f32=s3["states_per_s"] / f["states_per_s"])}
     return out
 
 

@@ -180,7 +180,10 @@ int nnmpc_qp_debug_factor_solve(nnmpc_qp* h, int32_t B, const float* dvec, const
  * entries for l < L-1 (the output layer has no bias).  with_uprev selects
  * RegulatorLayerWithUprev (d_in = 2 nx + 2 nu) or WithoutUprev (2 nx + nu).
  * xscale (nx) divides x and xs; NULL = ones.  ulb/uub (nu) clip the output;
- * NULL = no clipping (the Keras layer). */
+ * NULL = no clipping (the Keras layer).
+ * use_bf16: 0 = f32 MFMA GEMMs; 1 = bf16 operands with f32 accumulation (~2e-2 relative error on the CDU architecture);
+ * 2 = split bf16: activations and weights as pairs hi + lo of bf16 numbers, every layer ONE bf16 GEMM of three times the
+ * depth (hi hi' + hi lo' + lo hi'; only lo lo' is dropped): f32-grade results (~1e-5) from the bf16 matrix pipes. */
 int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims,
                     const double* const* W, const double* const* b, int32_t nx, int32_t nu,
                     int32_t with_uprev, const double* xscale, const double* ulb,

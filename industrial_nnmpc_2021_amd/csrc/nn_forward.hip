@@ -30,6 +30,7 @@ namespace {
 // columns padded to ldk.  Workgroups walk the SAMPLES: every scaled xs and every us value is computed once and written
 // to all of its places in both rows, segment by segment (no per-element source selection; consecutive lanes read
 // consecutive doubles).  Samples b >= B (batch padding) and the pad columns are zero.
+// (nn_assemble_split_k below: the same rows as the three bf16 planes [hi | hi | lo] of the split-bf16 path)
 template <class T>
 __global__ __launch_bounds__(256) void nn_assemble_k(T* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
                               int with_uprev, const double* __restrict__ x,
@@ -63,6 +64,43 @@ __global__ __launch_bounds__(256) void nn_assemble_k(T* __restrict__ in, int ldk
   }
 }
 
+// Split-bf16 input rows: [hi | hi | lo] planes of ldk columns each (rows of 3 ldk), value = hi + lo to ~2^-17 relative.
+__global__ __launch_bounds__(256) void nn_assemble_split_k(__bf16* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
+                              int with_uprev, const double* __restrict__ x,
+                              const double* __restrict__ uprev, const double* __restrict__ xs,
+                              const double* __restrict__ us, const float* __restrict__ inv_scale) {
+  const int o2 = nx + (with_uprev ? nu : 0);
+  const int din = o2 + nx + nu;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  auto put = [&](__bf16* row, int k, float v) {
+    const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+    row[k] = h; row[ldk + k] = h; row[2 * ldk + k] = l;
+  };
+  for (int b = blockIdx.x; b < Bp; b += gridDim.x) {
+    __bf16* d1 = in + (size_t)b * 3 * ldk;
+    __bf16* d2 = in + (size_t)(Bp + b) * 3 * ldk;
+    if (b >= B) {
+      for (int k = tid; k < 3 * ldk; k += nt) { d1[k] = (__bf16)0.f; d2[k] = (__bf16)0.f; }
+      continue;
+    }
+    const double* xa = x + (size_t)b * nx;
+    const double* xb = xs + (size_t)b * nx;
+    const double* ub = us + (size_t)b * nu;
+    for (int k = tid; k < nx; k += nt) {
+      const float sc = inv_scale[k];
+      const float xv = (float)xa[k] * sc, sv = (float)xb[k] * sc;
+      put(d1, k, xv); put(d1, o2 + k, sv);
+      put(d2, k, sv); put(d2, o2 + k, sv);
+    }
+    for (int k = tid; k < nu; k += nt) {
+      const float uv = (float)ub[k];
+      put(d1, o2 + nx + k, uv); put(d2, o2 + nx + k, uv);
+      if (with_uprev) { put(d1, nx + k, (float)uprev[(size_t)b * nu + k]); put(d2, nx + k, uv); }
+    }
+    for (int k = din + tid; k < ldk; k += nt) { put(d1, k, 0.f); put(d2, k, 0.f); }
+  }
+}
+
 __global__ void nn_combine_k(double* __restrict__ u, const float* __restrict__ o, int ldo, int Bp,
                              int B, int nu, const double* __restrict__ us,
                              const double* __restrict__ ulb, const double* __restrict__ uub,
@@ -89,7 +127,8 @@ struct nnmpc_nn {
   std::vector<float*> Wt;  // [npad][kpad] transposed weights (f32 path)
   std::vector<bf16raw*> Wt16;  // bf16 path: [n16][k16], k16 = layer input width rounded to 64 only (832 stays 832)
   std::vector<int> k16, n16, ldc16;  // ldc16 = row length of the layer's output = k16 of the next layer
-  int use_bf16;
+  int use_bf16;            // 0 f32, 1 bf16, 2 split bf16 (activations and weights as hi + lo pairs, three products per layer)
+  int split;               // use_bf16 == 2: 3 planes per activation row, weights stacked [hi ; lo ; hi] along K
   std::vector<float*> bias;  // [npad]
   int nx, nu, with_uprev, clip, max_batch;
   float* inv_scale;
@@ -125,14 +164,14 @@ void launch_layer(hipStream_t s, float* C, size_t ldc, const float* A, size_t ld
   hipLaunchKernelGGL((gemm_nt_f32_k<NB, RELU, BIAS>), grid, dim3(256), TileCfg<NB>::LDS_FLOATS * 4, s,
                      C, ldc, A, lda, Wt, ldb, K, bias);
 }
-template <int NB, bool RELU, bool BIAS, bool OUT16>
+template <int NB, bool RELU, bool BIAS, int OUT>
 void launch_layer16(hipStream_t s, void* C, int ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
                     size_t ldb, int M, int K, const float* bias) {
   const int ntm = M / NB, ntn = (ldc + NB - 1) / NB;
-  hipLaunchKernelGGL((gemm_nt_bf16_k<NB, RELU, BIAS, OUT16>), dim3(ntm * ntn), dim3(256), TileCfg16<NB>::LDS_BYTES, s,
+  hipLaunchKernelGGL((gemm_nt_bf16_k<NB, RELU, BIAS, OUT>), dim3(ntm * ntn), dim3(256), TileCfg16<NB>::LDS_BYTES, s,
                      C, ldc, A, lda, Wt, ldb, K, bias, ntm, ntn);
 }
-template <bool RELU, bool BIAS>
+template <bool RELU, bool BIAS, bool SPLIT>
 void launch_layer16_wide(hipStream_t s, __bf16* C, int ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
                          size_t ldb, int M, int K, const float* bias) {
   const int ntn = (ldc + WBN - 1) / WBN;
@@ -145,8 +184,8 @@ void launch_layer16_wide(hipStream_t s, __bf16* C, int ldc, const bf16raw* A, si
   }
   for (int m = 0; m < M; m += max_rows) {
     const int rows = std::min(max_rows, M - m), ntm = rows / WBM;
-    hipLaunchKernelGGL((gemm_nt_bf16_wide_k<RELU, BIAS>), dim3(8 * npg * ntn), dim3(512), W_LDS_BYTES, s,
-                       C + (size_t)m * ldc, ldc, A + (size_t)m * lda, lda, Wt, ldb, K, bias, ntm, ntn, npg);
+    hipLaunchKernelGGL((gemm_nt_bf16_wide_k<RELU, BIAS, SPLIT>), dim3(8 * npg * ntn), dim3(512), W_LDS_BYTES, s,
+                       C + (size_t)m * ldc * (SPLIT ? 3 : 1), ldc, A + (size_t)m * lda, lda, Wt, ldb, K, bias, ntm, ntn, npg);
   }
 }
 }  // namespace
@@ -165,7 +204,8 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("nnmpc_nn_create: no HIP device available (no CPU fallback)"); return NNMPC_EHIP; }
   nnmpc_nn* h = new nnmpc_nn();
   hipGetDevice(&h->device);
-  h->use_bf16 = use_bf16 != 0;
+  h->use_bf16 = use_bf16 == 2 ? 2 : (use_bf16 != 0);
+  h->split = h->use_bf16 == 2;
   h->nlayers = nlayers; h->nx = nx; h->nu = nu; h->with_uprev = with_uprev; h->clip = ulb != nullptr;
   h->max_batch = ((std::max(max_batch, 1) + 127) / 128) * 128;
   h->gemm_ms = h->total_ms = h->hidden_ms = 0; h->hidden_launches = 0;
@@ -174,8 +214,10 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   hipEventCreate(&h->e0); hipEventCreate(&h->e1);
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
   hipFuncSetAttribute((const void*)gemm_nt_f32_k<128, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
-  hipFuncSetAttribute((const void*)gemm_nt_bf16_k<128, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg16<128>::LDS_BYTES);
-  hipFuncSetAttribute((const void*)gemm_nt_bf16_wide_k<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_nt_bf16_k<128, true, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg16<128>::LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_nt_bf16_k<128, true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg16<128>::LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_nt_bf16_wide_k<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
+  hipFuncSetAttribute((const void*)gemm_nt_bf16_wide_k<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
   h->maxw = 0;
   int rc = 0;
   for (int l = 0; l < nlayers && !rc; ++l) {
@@ -204,13 +246,17 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
       const int nb = (!lastl && ldc >= 2 * WBN) ? WBN : (dims[l + 1] > 64 ? 128 : 64);   // WBN: the wide-tile kernel
       const int n16 = ((ldc + nb - 1) / nb) * nb;
       h->k16.push_back(k16); h->n16.push_back(n16); h->ldc16.push_back(ldc);
-      std::vector<bf16raw> w16((size_t)(n16 + 64) * k16, 0);   // + 64 zero rows: the wide kernel's staging loads may run past the last tile
+      // split path: rows of 3 k16 = [hi ; lo ; hi] against the activation planes [hi | hi | lo]
+      const int kw = h->split ? 3 * k16 : k16;
+      std::vector<bf16raw> w16((size_t)(n16 + 64) * kw, 0);   // + 64 zero rows: the wide kernel's staging loads may run past the last tile
+      auto rne = [](float f) { unsigned u; memcpy(&u, &f, 4); u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; return (bf16raw)u; };   // round to nearest even
+      auto tof = [](bf16raw b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
       for (int i = 0; i < dims[l]; ++i)
-        for (int o = 0; o < dims[l + 1]; ++o) {   // round to nearest even
+        for (int o = 0; o < dims[l + 1]; ++o) {
           const float f = (float)W[l][(size_t)i * dims[l + 1] + o];
-          unsigned u; memcpy(&u, &f, 4);
-          u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-          w16[(size_t)o * k16 + i] = (bf16raw)u;
+          const bf16raw hi = rne(f);
+          w16[(size_t)o * kw + i] = hi;
+          if (h->split) { w16[(size_t)o * kw + k16 + i] = rne(f - tof(hi)); w16[(size_t)o * kw + 2 * k16 + i] = hi; }
         }
       bf16raw* d16 = nullptr;
       rc = nn_alloc(h, &d16, w16.size()); if (rc) break;
@@ -226,6 +272,11 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   if (!rc) rc = nn_alloc(h, &h->uub, nu);
   if (!rc && ulb) { hipMemcpy(h->ulb, ulb, nu * 8, hipMemcpyHostToDevice); hipMemcpy(h->uub, uub, nu * 8, hipMemcpyHostToDevice); }
   const size_t MB = h->max_batch;
+  if (h->split) {                                          // rows of three bf16 planes of up to max(k16, ldc16) columns, in units of float
+    int w = 0;
+    for (int l = 0; l < nlayers; ++l) w = std::max(w, std::max(h->k16[l], h->ldc16[l]));
+    h->maxw = std::max(h->maxw, (3 * w * 2 + 3) / 4);
+  }
   if (!rc) rc = nn_alloc(h, &h->act[0], 2 * MB * h->maxw);
   if (!rc) rc = nn_alloc(h, &h->act[1], 2 * MB * h->maxw);
   if (!rc) rc = nn_alloc(h, &h->sx, MB * nx);
@@ -276,7 +327,10 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       dx = x + (size_t)b0 * nx; dxs = xs + (size_t)b0 * nx; dus = us + (size_t)b0 * nu;
       dup = h->with_uprev ? uprev + (size_t)b0 * nu : nullptr; du = u + (size_t)b0 * nu;
     }
-    if (h->use_bf16)
+    if (h->split)
+      hipLaunchKernelGGL(nn_assemble_split_k, dim3(8192), dim3(256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
+                         h->kpad[0], Bp, nb, nx, nu, h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
+    else if (h->use_bf16)
       hipLaunchKernelGGL(nn_assemble_k<__bf16>, dim3(8192), dim3(256), 0, s, reinterpret_cast<__bf16*>(h->act[0]),
                          h->kpad[0], Bp, nb, nx, nu, h->with_uprev, dx, dup, dxs, dus, h->inv_scale);
     else
@@ -293,15 +347,18 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       if (last) hipEventRecord(h->eg[3 * nsub + 1], s);    // end of the hidden layers
       if (h->use_bf16) {
         const bf16raw* A16 = reinterpret_cast<const bf16raw*>(A);
-        const int K16 = h->k16[l], ldc = h->ldc16[l];
+        const int K16 = h->split ? 3 * h->k16[l] : h->k16[l], ldc = h->ldc16[l];   // split: one GEMM of three times the depth
         if (!last && ldc >= 2 * WBN) {
-          launch_layer16_wide<true, true>(s, reinterpret_cast<__bf16*>(C), ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          if (h->split) launch_layer16_wide<true, true, true>(s, reinterpret_cast<__bf16*>(C), ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          else launch_layer16_wide<true, true, false>(s, reinterpret_cast<__bf16*>(C), ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
         } else if (h->n16[l] % 128 == 0) {
-          if (last) launch_layer16<128, false, false, false>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
-          else launch_layer16<128, true, true, true>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          if (last) launch_layer16<128, false, false, 0>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
+          else if (h->split) launch_layer16<128, true, true, 2>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          else launch_layer16<128, true, true, 1>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
         } else {
-          if (last) launch_layer16<64, false, false, false>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
-          else launch_layer16<64, true, true, true>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          if (last) launch_layer16<64, false, false, 0>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
+          else if (h->split) launch_layer16<64, true, true, 2>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          else launch_layer16<64, true, true, 1>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
         }
       } else if (N % 128 == 0) {
         if (last) launch_layer<128, false, false>(s, C, N, A, K, h->Wt[l], K, M, N, K, nullptr);

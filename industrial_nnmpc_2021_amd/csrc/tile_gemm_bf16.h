@@ -77,7 +77,11 @@ __device__ __forceinline__ void store_chunk16(const f32x4 (&r)[TileCfg16<NB>::LD
 // columns of one row per register quad, so the epilogue stores 8 (bf16) / 16 (f32) bytes per lane.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int NB, bool RELU, bool BIAS, bool OUT_BF16>
+// OUT: 0 f32, 1 bf16, 2 split bf16 -- three planes of ldc columns in rows of 3 ldc: [hi | hi | lo], hi = bf16(x), lo = bf16(x - hi):
+// the A operand of a next layer whose weights are stacked [hi ; lo ; hi] along K, so that ONE bf16 GEMM of three times the
+// depth forms  hi hi' + hi lo' + lo hi'  -- the product to ~2^-17 relative (only lo lo' is dropped), f32-grade results
+// from the bf16 matrix pipes (nnmpc_nn_create, use_bf16 = 2).
+template <int NB, bool RELU, bool BIAS, int OUT>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, int ldc,
                                                       const bf16raw* __restrict__ A, size_t lda,
                                                       const bf16raw* __restrict__ B, size_t ldb, int K,
@@ -138,8 +142,15 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, int
             float x = acc[mi][mj][4 * j + e] + bv[e];
             v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
           }
-          const size_t o = (size_t)(row0 + mi * 32) * ldc + col;
-          if (OUT_BF16) {
+          const size_t o = (size_t)(row0 + mi * 32) * (OUT == 2 ? 3 * ldc : ldc) + col;
+          if (OUT == 2) {
+            const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            const bf16x4 l = {(__bf16)(v[0] - (float)h[0]), (__bf16)(v[1] - (float)h[1]), (__bf16)(v[2] - (float)h[2]), (__bf16)(v[3] - (float)h[3])};
+            __bf16* cp = reinterpret_cast<__bf16*>(Cv) + o;
+            *reinterpret_cast<bf16x4*>(cp) = h;
+            *reinterpret_cast<bf16x4*>(cp + ldc) = h;
+            *reinterpret_cast<bf16x4*>(cp + 2 * ldc) = l;
+          } else if (OUT == 1) {
             bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(Cv) + o) = h;
           } else {
@@ -168,7 +179,8 @@ constexpr int WBM = 256, WBN = 208, WNT = 7;               // WNT: column tiles 
 constexpr int W_STAGE = (WBM + 256) * 64;                  // bf16 elements per stage (A, then B padded to 256 rows: staging writes need no branch)
 constexpr int W_LDS_BYTES = 2 * W_STAGE * 2 + 1024;        // two stages + the workgroup's bias values
 
-template <bool RELU, bool BIAS>
+// SPLIT: the output goes out as the three planes [hi | hi | lo] of gemm_nt_bf16_k's OUT = 2 (rows of 3 ldc elements).
+template <bool RELU, bool BIAS, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ C, int ldc,
                                                            const bf16raw* __restrict__ A, size_t lda,
                                                            const bf16raw* __restrict__ B, size_t ldb, int K,
@@ -301,41 +313,52 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
   auto epilogue = [&](int pc, bf16raw* stage) {
     unsigned char* er = reinterpret_cast<unsigned char*>(stage) + wave * (32 * ESTRIDE);
     const int m0 = (p0 + pstride * pc) * WBM;
-    __bf16* Cw = C + (size_t)(m0 + 64 * wm) * ldc + n0 + 16 * WNT * wn;
+    const size_t ldr = SPLIT ? (size_t)3 * ldc : (size_t)ldc;   // elements per row of C
+    __bf16* Cw = C + (size_t)(m0 + 64 * wm) * ldr + n0 + 16 * WNT * wn;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+#pragma unroll 1
+      for (int plane = 0; plane < (SPLIT ? 2 : 1); ++plane) { // 0: hi (bf16 of the value) -> columns [0, ldc) and, SPLIT, [ldc, 2 ldc);
+#pragma unroll                                              //    1 (SPLIT): lo (bf16 of value - hi) -> [2 ldc, 3 ldc)
+        for (int nt = 0; nt < WNT; ++nt) {
+          if (nt < WNT - 1 || wn == 0) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + 16 * (WNT * wn + nt) + 4 * g);
 #pragma unroll
-      for (int nt = 0; nt < WNT; ++nt) {
-        if (nt < WNT - 1 || wn == 0) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + 16 * (WNT * wn + nt) + 4 * g);
+            for (int m2 = 0; m2 < 2; ++m2) {
+              float v[4];
 #pragma unroll
-          for (int m2 = 0; m2 < 2; ++m2) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = acc[2 * h + m2][nt][e] + bv[e];
-              v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
-              acc[2 * h + m2][nt][e] = 0.f;
+              for (int e = 0; e < 4; ++e) {
+                const float x = acc[2 * h + m2][nt][e] + bv[e];
+                v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
+                if (!SPLIT || plane == 1) acc[2 * h + m2][nt][e] = 0.f;
+              }
+              bf16x4 hv = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              if (SPLIT && plane == 1) hv = bf16x4{(__bf16)(v[0] - (float)hv[0]), (__bf16)(v[1] - (float)hv[1]), (__bf16)(v[2] - (float)hv[2]), (__bf16)(v[3] - (float)hv[3])};
+              *reinterpret_cast<bf16x4*>(er + (16 * m2 + lr) * ESTRIDE + 32 * nt + 8 * g) = hv;
             }
-            const bf16x4 hv = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(er + (16 * m2 + lr) * ESTRIDE + 32 * nt + 8 * g) = hv;
           }
         }
-      }
-      int row = lane / npc, c = lane - row * npc;            // piece q = lane + 64 i -> (row, c) = (q / npc, q % npc)
-      const int dr = 64 / npc, dc = 64 % npc;
+        __bf16* Cp = Cw + (SPLIT && plane == 1 ? 2 * (size_t)ldc : 0);
+        int row = lane / npc, c = lane - row * npc;          // piece q = lane + 64 i -> (row, c) = (q / npc, q % npc)
+        const int dr = 64 / npc, dc = 64 % npc;
 #pragma unroll 1
-      for (int i = 0; i < WNT; i += 2) {                     // two pieces per trip (their LDS reads overlap); not unrolled
-        int row1 = row + dr, c1 = c + dc;                    // further: the registers belong to the loads in flight
-        if (c1 >= npc) { c1 -= npc; ++row1; }
-        const bool ok0 = row < 32, ok1 = i + 1 < WNT && row1 < 32;
-        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-        if (ok0) v0 = *reinterpret_cast<const u32x4*>(er + row * ESTRIDE + 16 * c);
-        if (ok1) v1 = *reinterpret_cast<const u32x4*>(er + row1 * ESTRIDE + 16 * c1);
-        if (ok0 && n0 + 16 * WNT * wn + 8 * c < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)(32 * h + row) * ldc + 8 * c) = v0;
-        if (ok1 && n0 + 16 * WNT * wn + 8 * c1 < ldc) *reinterpret_cast<u32x4*>(Cw + (size_t)(32 * h + row1) * ldc + 8 * c1) = v1;
-        row = row1 + dr; c = c1 + dc;
-        if (c >= npc) { c -= npc; ++row; }
+        for (int i = 0; i < WNT; i += 2) {                   // two pieces per trip (their LDS reads overlap); not unrolled
+          int row1 = row + dr, c1 = c + dc;                  // further: the registers belong to the loads in flight
+          if (c1 >= npc) { c1 -= npc; ++row1; }
+          const bool ok0 = row < 32, ok1 = i + 1 < WNT && row1 < 32;
+          u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+          if (ok0) v0 = *reinterpret_cast<const u32x4*>(er + row * ESTRIDE + 16 * c);
+          if (ok1) v1 = *reinterpret_cast<const u32x4*>(er + row1 * ESTRIDE + 16 * c1);
+          const bool in0 = ok0 && n0 + 16 * WNT * wn + 8 * c < ldc, in1 = ok1 && n0 + 16 * WNT * wn + 8 * c1 < ldc;
+          if (in0) *reinterpret_cast<u32x4*>(Cp + (size_t)(32 * h + row) * ldr + 8 * c) = v0;
+          if (in1) *reinterpret_cast<u32x4*>(Cp + (size_t)(32 * h + row1) * ldr + 8 * c1) = v1;
+          if (SPLIT && plane == 0) {                          // the hi plane a second time
+            if (in0) *reinterpret_cast<u32x4*>(Cp + ldc + (size_t)(32 * h + row) * ldr + 8 * c) = v0;
+            if (in1) *reinterpret_cast<u32x4*>(Cp + ldc + (size_t)(32 * h + row1) * ldr + 8 * c1) = v1;
+          }
+          row = row1 + dr; c = c1 + dc;
+          if (c >= npc) { c -= npc; ++row; }
+        }
       }
     }
     __syncthreads();                                        // the stage goes back to the pipeline

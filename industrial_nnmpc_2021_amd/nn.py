@@ -13,7 +13,11 @@ from . import _lib
 
 
 class StructuredNN:
-    """``weights``: Keras get_weights() order [W1 (in x h), b1, ..., Wout (h x nu)]."""
+    """``weights``: Keras get_weights() order [W1 (in x h), b1, ..., Wout (h x nu)].
+
+    ``use_bf16``: False -- f32 MFMA GEMMs; True -- bf16 operands, f32 accumulation (~2e-2 relative error on the CDU
+    architecture); "split" (or 2) -- activations and weights as bf16 pairs hi + lo, every layer ONE bf16 GEMM of three times
+    the depth (hi hi' + hi lo' + lo hi'): f32-grade results (~1e-5) from the bf16 matrix pipes."""
 
     def __init__(self, weights, nx, nu, *, nnwithuprev=True, xscale=None, ulb=None, uub=None,
                  max_batch=65536, use_bf16=False):
@@ -35,7 +39,8 @@ class StructuredNN:
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         self._h = C.c_void_p()
         _lib.check(lib.nnmpc_nn_create(C.byref(self._h), L, dims_c, Wp, bp, nx, nu, int(nnwithuprev),
-                                       p(xs_), p(lb_), p(ub_), int(use_bf16), max_batch), "nnmpc_nn_create")
+                                       p(xs_), p(lb_), p(ub_), 2 if use_bf16 in ("split", 2) else int(bool(use_bf16)), max_batch),
+                   "nnmpc_nn_create")
         self._lib = lib
 
     def close(self):

@@ -117,7 +117,7 @@ def test_cdu_operating_points(sx):
     u.free(); qp.close()
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 3e-2), ("bf16x3", 1e-4)])
 def test_nn_config_1m_states(mode, tol):
     """[536, 832, 832, 832, 32] WithoutUprev (cdu_train.py:33, :77-80), 1 048 576 states through the device entry point."""
     from industrial_nnmpc_2021_amd import _lib
@@ -137,7 +137,7 @@ def test_nn_config_1m_states(mode, tol):
     D = _lib.DeviceArray
     dx, dxs, dus, du = D.from_host(x), D.from_host(xs), D.from_host(us), D((B, nu), np.float64)
     net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu), max_batch=262144,
-                       use_bf16=(mode == "bf16"))
+                       use_bf16={"f32": False, "bf16": True, "bf16x3": "split"}[mode])
     net.forward_device(B, dx, None, dxs, dus, du)
     u = du.to_host()
     rows = np.concatenate(([7, 0, B - 1, 262143, 262144], rng.choice(B, 4091, replace=False)))

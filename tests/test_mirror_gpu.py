@@ -192,6 +192,35 @@ def test_nn_bf16_wide_tile_kernel_shapes(hid, withu, B, mb):
     net.close()
 
 
+@pytest.mark.parametrize("hid,withu,B,mb", [(832, False, 700, 512), (960, True, 300, 256), (416, False, 257, 128),   # wide-tile kernel
+                                            (64, True, 200, 128), (192, False, 333, 256)])                          # 64 / 128-tile kernel
+def test_nn_split_bf16_is_f32_grade(hid, withu, B, mb):
+    """use_bf16 = "split": activations and weights as bf16 pairs hi + lo, one bf16 GEMM of three times the depth per layer
+    (hi hi' + hi lo' + lo hi').  Against the fp64 oracle (lib/controller_evaluation.py:863-892) the result must be as good as
+    the f32 path's: 1e-4 of the output scale (the plain bf16 path: 3e-2), on both GEMM kernels, with and without uprev,
+    several sub-batches and a partial last column tile."""
+    from industrial_nnmpc_2021_amd.nn import StructuredNN
+    from oracle import nn as onn
+    rng = np.random.default_rng(7 * hid + B)
+    nx, nu = (252, 32) if hid >= 416 else (12, 6)
+    dims = [2 * nx + (2 if withu else 1) * nu, hid, hid, hid, nu]
+    W = []
+    for i in range(4):
+        W.append(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i]))
+        if i < 3:
+            W.append(0.05 * rng.standard_normal(dims[i + 1]))
+    x, xs = rng.standard_normal((B, nx)), 0.3 * rng.standard_normal((B, nx))
+    us, up = rng.uniform(-.5, .5, (B, nu)), rng.uniform(-1, 1, (B, nu))
+    x[0] = xs[0]; up[0] = us[0]                                # steady state: u = clip(us) exactly, whatever the weights
+    xscale = rng.uniform(0.5, 2.0, nx)
+    net = StructuredNN(W, nx, nu, nnwithuprev=withu, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu), max_batch=mb, use_bf16="split")
+    u = net.forward(x, up if withu else None, xs, us)
+    net.close()
+    ref = onn.control_input(W, x, up if withu else None, xs, us, xscale, -np.ones(nu), np.ones(nu), withu)
+    assert np.abs(u - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), np.abs(u - ref).max()
+    assert np.array_equal(u[0], np.clip(us[0], -1, 1))
+
+
 def test_nn_bf16_wide_tile_kernel_row_slices(monkeypatch):
     """The wide-tile kernel addresses its input with 32-bit byte offsets; the launcher cuts inputs of 2^31 bytes and
     more into row slices.  NNMPC_WIDE_MAX_ROWS forces that path on a small batch: same result as one slice."""
