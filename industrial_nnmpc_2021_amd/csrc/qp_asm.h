@@ -1450,68 +1450,84 @@ __device__ __forceinline__ int asm_frow(int i) { return i * (i + 3) / 2; }
 // pivot element goes round by v_readlane, the reciprocals of the diagonal are formed once, in parallel: one LDS read and two
 // FMAs per lane in the dependent chain of a step.  (The first version kept v in LDS -- four LDS round trips and an fp64
 // division per step: 20 us per substitution at 100 bounds, two or three substitutions per iteration of asm_tail_k.)
-static_assert(ASM_FM <= 192, "asm_fwd / asm_bwd hold the vector in three registers per lane");
-__device__ __forceinline__ void asm_fwd(const double* Ld, double* v, int m, int lane) {
-  double x[3], idg[3], ln[3];
-  const double* rowp[3];                                     // row of element lane + 64 u (clamped to the last row: reads stay inside L)
+static_assert(ASM_FM <= 192, "asm_fwd / asm_bwd hold the vector in at most three registers per lane");
+// (NU = registers per lane: the loop is bound by instruction issue, ~25 instructions per step and register -- sets of at most 64
+// bounds run the NU = 1 instance, at most 128 the NU = 2 one)
+template <int NU>
+__device__ __forceinline__ void asm_fwd_t(const double* Ld, double* v, int m, int lane) {
+  double x[NU], idg[NU], ln[NU];
+  const double* rowp[NU];                                    // row of element lane + 64 u (clamped to the last row: reads stay inside L)
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int i = lane + 64 * u, ic = min(i, m - 1);
     rowp[u] = Ld + asm_frow(ic);
     x[u] = i < m ? v[i] : 0.0;
     idg[u] = i < m ? 1.0 / rowp[u][i] : 0.0;
     ln[u] = rowp[u][0];
   }
-  // branch-free steps, the three LDS reads of step k + 1 issued before the arithmetic of step k (entries at or above the
+  // branch-free steps, the LDS reads of step k + 1 issued before the arithmetic of step k (entries at or above the
   // diagonal are read and not used)
   for (int k = 0; k < m; ++k) {
     const int ku = k >> 6, kl = k & 63;
-    double lc[3];
+    double lc[NU];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { lc[u] = ln[u]; ln[u] = rowp[u][min(k + 1, m - 1)]; }
-    const double t = (ku == 0 ? x[0] * idg[0] : (ku == 1 ? x[1] * idg[1] : x[2] * idg[2]));
+    for (int u = 0; u < NU; ++u) { lc[u] = ln[u]; ln[u] = rowp[u][min(k + 1, m - 1)]; }
+    double t = x[0] * idg[0];
+#pragma unroll
+    for (int u = 1; u < NU; ++u) t = ku == u ? x[u] * idg[u] : t;
     const double yk = rdlane_d(t, kl);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int i = lane + 64 * u;
       const double upd = x[u] - lc[u] * yk;
       x[u] = i == k ? yk : ((i > k && i < m) ? upd : x[u]);
     }
   }
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { const int i = lane + 64 * u; if (i < m) v[i] = x[u]; }
+  for (int u = 0; u < NU; ++u) { const int i = lane + 64 * u; if (i < m) v[i] = x[u]; }
   ASM_FENCE();
 }
+__device__ __forceinline__ void asm_fwd(const double* Ld, double* v, int m, int lane) {
+  if (m <= 64) asm_fwd_t<1>(Ld, v, m, lane);
+  else if (m <= 128) asm_fwd_t<2>(Ld, v, m, lane);
+  else asm_fwd_t<3>(Ld, v, m, lane);
+}
 // v <- L^-T v
-__device__ __forceinline__ void asm_bwd(const double* Ld, double* v, int m, int lane) {
-  double x[3], idg[3];
+template <int NU>
+__device__ __forceinline__ void asm_bwd_t(const double* Ld, double* v, int m, int lane) {
+  double x[NU], idg[NU], ln[NU];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int i = lane + 64 * u;
     x[u] = i < m ? v[i] : 0.0;
     idg[u] = i < m ? 1.0 / Ld[asm_frow(i) + i] : 0.0;
+    ln[u] = m > 0 ? Ld[asm_frow(m - 1) + min(i, m - 1)] : 0.0;
   }
-  double ln[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) ln[u] = m > 0 ? Ld[asm_frow(m - 1) + min(lane + 64 * u, m - 1)] : 0.0;
   for (int k = m - 1; k >= 0; --k) {
     const int ku = k >> 6, kl = k & 63;
-    double lc[3];
+    double lc[NU];
     const double* rown = Ld + asm_frow(max(k - 1, 0));       // row k - 1 for the next step: columns 0..k-1 (k is its spare slot)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { lc[u] = ln[u]; ln[u] = rown[min(lane + 64 * u, max(k - 1, 0))]; }
-    const double t = (ku == 0 ? x[0] * idg[0] : (ku == 1 ? x[1] * idg[1] : x[2] * idg[2]));
+    for (int u = 0; u < NU; ++u) { lc[u] = ln[u]; ln[u] = rown[min(lane + 64 * u, max(k - 1, 0))]; }
+    double t = x[0] * idg[0];
+#pragma unroll
+    for (int u = 1; u < NU; ++u) t = ku == u ? x[u] * idg[u] : t;
     const double lk = rdlane_d(t, kl);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int i = lane + 64 * u;
       const double upd = x[u] - lc[u] * lk;
       x[u] = i == k ? lk : (i < k ? upd : x[u]);
     }
   }
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { const int i = lane + 64 * u; if (i < m) v[i] = x[u]; }
+  for (int u = 0; u < NU; ++u) { const int i = lane + 64 * u; if (i < m) v[i] = x[u]; }
   ASM_FENCE();
+}
+__device__ __forceinline__ void asm_bwd(const double* Ld, double* v, int m, int lane) {
+  if (m <= 64) asm_bwd_t<1>(Ld, v, m, lane);
+  else if (m <= 128) asm_bwd_t<2>(Ld, v, m, lane);
+  else asm_bwd_t<3>(Ld, v, m, lane);
 }
 
 __global__ __launch_bounds__(256) void asm_taillist_k(AsmDev d) {
