@@ -30,7 +30,7 @@ namespace {
 // columns padded to ldk.  Workgroups walk the SAMPLES: every scaled xs and every us value is computed once and written
 // to all of its places in both rows, segment by segment (no per-element source selection; consecutive lanes read
 // consecutive doubles).  Samples b >= B (batch padding) and the pad columns are zero.
-// (nn_assemble_split_k below: the same rows as the three bf16 planes [hi | hi | lo] of the split-bf16 path)
+// (nn_assemble_split_k below: the same rows as the two bf16 planes [hi | lo] of the split-bf16 path)
 template <class T>
 __global__ __launch_bounds__(256) void nn_assemble_k(T* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
                               int with_uprev, const double* __restrict__ x,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void nn_assemble_k(T* __restrict__ in, int ldk
   }
 }
 
-// Split-bf16 input rows: [hi | hi | lo] planes of ldk columns each (rows of 3 ldk), value = hi + lo to ~2^-17 relative.
+// Split-bf16 input rows: [hi | lo] planes of ldk columns each (rows of 2 ldk), value = hi + lo to ~2^-17 relative.
 __global__ __launch_bounds__(256) void nn_assemble_split_k(__bf16* __restrict__ in, int ldk, int Bp, int B, int nx, int nu,
                               int with_uprev, const double* __restrict__ x,
                               const double* __restrict__ uprev, const double* __restrict__ xs,
@@ -74,13 +74,13 @@ __global__ __launch_bounds__(256) void nn_assemble_split_k(__bf16* __restrict__ 
   const int tid = threadIdx.x, nt = blockDim.x;
   auto put = [&](__bf16* row, int k, float v) {
     const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
-    row[k] = h; row[ldk + k] = h; row[2 * ldk + k] = l;
+    row[k] = h; row[ldk + k] = l;
   };
   for (int b = blockIdx.x; b < Bp; b += gridDim.x) {
-    __bf16* d1 = in + (size_t)b * 3 * ldk;
-    __bf16* d2 = in + (size_t)(Bp + b) * 3 * ldk;
+    __bf16* d1 = in + (size_t)b * 2 * ldk;
+    __bf16* d2 = in + (size_t)(Bp + b) * 2 * ldk;
     if (b >= B) {
-      for (int k = tid; k < 3 * ldk; k += nt) { d1[k] = (__bf16)0.f; d2[k] = (__bf16)0.f; }
+      for (int k = tid; k < 2 * ldk; k += nt) { d1[k] = (__bf16)0.f; d2[k] = (__bf16)0.f; }
       continue;
     }
     const double* xa = x + (size_t)b * nx;
@@ -128,7 +128,7 @@ struct nnmpc_nn {
   std::vector<bf16raw*> Wt16;  // bf16 path: [n16][k16], k16 = layer input width rounded to 64 only (832 stays 832)
   std::vector<int> k16, n16, ldc16;  // ldc16 = row length of the layer's output = k16 of the next layer
   int use_bf16;            // 0 f32, 1 bf16, 2 split bf16 (activations and weights as hi + lo pairs, three products per layer)
-  int split;               // use_bf16 == 2: 3 planes per activation row, weights stacked [hi ; lo ; hi] along K
+  int split;               // use_bf16 == 2: activation rows [hi | lo], walked hi, hi, lo against weights stacked [hi ; lo ; hi] along K
   std::vector<float*> bias;  // [npad]
   int nx, nu, with_uprev, clip, max_batch;
   float* inv_scale;
@@ -166,10 +166,10 @@ void launch_layer(hipStream_t s, float* C, size_t ldc, const float* A, size_t ld
 }
 template <int NB, bool RELU, bool BIAS, int OUT>
 void launch_layer16(hipStream_t s, void* C, int ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
-                    size_t ldb, int M, int K, const float* bias) {
+                    size_t ldb, int M, int K, const float* bias, int nk0 = 0) {
   const int ntm = M / NB, ntn = (ldc + NB - 1) / NB;
   hipLaunchKernelGGL((gemm_nt_bf16_k<NB, RELU, BIAS, OUT>), dim3(ntm * ntn), dim3(256), TileCfg16<NB>::LDS_BYTES, s,
-                     C, ldc, A, lda, Wt, ldb, K, bias, ntm, ntn);
+                     C, ldc, A, lda, Wt, ldb, K, bias, ntm, ntn, nk0);
 }
 template <bool RELU, bool BIAS, bool SPLIT>
 void launch_layer16_wide(hipStream_t s, __bf16* C, int ldc, const bf16raw* A, size_t lda, const bf16raw* Wt,
@@ -185,7 +185,7 @@ void launch_layer16_wide(hipStream_t s, __bf16* C, int ldc, const bf16raw* A, si
   for (int m = 0; m < M; m += max_rows) {
     const int rows = std::min(max_rows, M - m), ntm = rows / WBM;
     hipLaunchKernelGGL((gemm_nt_bf16_wide_k<RELU, BIAS, SPLIT>), dim3(8 * npg * ntn), dim3(512), W_LDS_BYTES, s,
-                       C + (size_t)m * ldc * (SPLIT ? 3 : 1), ldc, A + (size_t)m * lda, lda, Wt, ldb, K, bias, ntm, ntn, npg);
+                       C + (size_t)m * ldc * (SPLIT ? 2 : 1), ldc, A + (size_t)m * lda, lda, Wt, ldb, K, bias, ntm, ntn, npg);
   }
 }
 }  // namespace
@@ -246,7 +246,7 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
       const int nb = (!lastl && ldc >= 2 * WBN) ? WBN : (dims[l + 1] > 64 ? 128 : 64);   // WBN: the wide-tile kernel
       const int n16 = ((ldc + nb - 1) / nb) * nb;
       h->k16.push_back(k16); h->n16.push_back(n16); h->ldc16.push_back(ldc);
-      // split path: rows of 3 k16 = [hi ; lo ; hi] against the activation planes [hi | hi | lo]
+      // split path: rows of 3 k16 = [hi ; lo ; hi] against the activation planes walked hi, hi, lo
       const int kw = h->split ? 3 * k16 : k16;
       std::vector<bf16raw> w16((size_t)(n16 + 64) * kw, 0);   // + 64 zero rows: the wide kernel's staging loads may run past the last tile
       auto rne = [](float f) { unsigned u; memcpy(&u, &f, 4); u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; return (bf16raw)u; };   // round to nearest even
@@ -272,10 +272,10 @@ int nnmpc_nn_create(nnmpc_nn** out, int32_t nlayers, const int32_t* dims, const 
   if (!rc) rc = nn_alloc(h, &h->uub, nu);
   if (!rc && ulb) { hipMemcpy(h->ulb, ulb, nu * 8, hipMemcpyHostToDevice); hipMemcpy(h->uub, uub, nu * 8, hipMemcpyHostToDevice); }
   const size_t MB = h->max_batch;
-  if (h->split) {                                          // rows of three bf16 planes of up to max(k16, ldc16) columns, in units of float
+  if (h->split) {                                          // rows of two bf16 planes of up to max(k16, ldc16) columns, in units of float
     int w = 0;
     for (int l = 0; l < nlayers; ++l) w = std::max(w, std::max(h->k16[l], h->ldc16[l]));
-    h->maxw = std::max(h->maxw, (3 * w * 2 + 3) / 4);
+    h->maxw = std::max(h->maxw, (2 * w * 2 + 3) / 4);
   }
   if (!rc) rc = nn_alloc(h, &h->act[0], 2 * MB * h->maxw);
   if (!rc) rc = nn_alloc(h, &h->act[1], 2 * MB * h->maxw);
@@ -347,18 +347,21 @@ int nnmpc_nn_forward(nnmpc_nn* h, int32_t B, const double* x, const double* upre
       if (last) hipEventRecord(h->eg[3 * nsub + 1], s);    // end of the hidden layers
       if (h->use_bf16) {
         const bf16raw* A16 = reinterpret_cast<const bf16raw*>(A);
-        const int K16 = h->split ? 3 * h->k16[l] : h->k16[l], ldc = h->ldc16[l];   // split: one GEMM of three times the depth
+        // split: one GEMM of three times the depth (K16), rows of two planes (lda), nk0 chunks per plane
+        const int K16 = h->split ? 3 * h->k16[l] : h->k16[l], ldc = h->ldc16[l];
+        const size_t lda = h->split ? 2 * (size_t)h->k16[l] : (size_t)h->k16[l];
+        const int nk0 = h->split ? h->k16[l] / 64 : 0;
         if (!last && ldc >= 2 * WBN) {
-          if (h->split) launch_layer16_wide<true, true, true>(s, reinterpret_cast<__bf16*>(C), ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
-          else launch_layer16_wide<true, true, false>(s, reinterpret_cast<__bf16*>(C), ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          if (h->split) launch_layer16_wide<true, true, true>(s, reinterpret_cast<__bf16*>(C), ldc, A16, lda, h->Wt16[l], K16, M, K16, h->bias[l]);
+          else launch_layer16_wide<true, true, false>(s, reinterpret_cast<__bf16*>(C), ldc, A16, lda, h->Wt16[l], K16, M, K16, h->bias[l]);
         } else if (h->n16[l] % 128 == 0) {
-          if (last) launch_layer16<128, false, false, 0>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
-          else if (h->split) launch_layer16<128, true, true, 2>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
-          else launch_layer16<128, true, true, 1>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          if (last) launch_layer16<128, false, false, 0>(s, C, ldc, A16, lda, h->Wt16[l], K16, M, K16, nullptr, nk0);
+          else if (h->split) launch_layer16<128, true, true, 2>(s, C, ldc, A16, lda, h->Wt16[l], K16, M, K16, h->bias[l], nk0);
+          else launch_layer16<128, true, true, 1>(s, C, ldc, A16, lda, h->Wt16[l], K16, M, K16, h->bias[l]);
         } else {
-          if (last) launch_layer16<64, false, false, 0>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, nullptr);
-          else if (h->split) launch_layer16<64, true, true, 2>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
-          else launch_layer16<64, true, true, 1>(s, C, ldc, A16, K16, h->Wt16[l], K16, M, K16, h->bias[l]);
+          if (last) launch_layer16<64, false, false, 0>(s, C, ldc, A16, lda, h->Wt16[l], K16, M, K16, nullptr, nk0);
+          else if (h->split) launch_layer16<64, true, true, 2>(s, C, ldc, A16, lda, h->Wt16[l], K16, M, K16, h->bias[l], nk0);
+          else launch_layer16<64, true, true, 1>(s, C, ldc, A16, lda, h->Wt16[l], K16, M, K16, h->bias[l]);
         }
       } else if (N % 128 == 0) {
         if (last) launch_layer<128, false, false>(s, C, N, A, K, h->Wt[l], K, M, N, K, nullptr);

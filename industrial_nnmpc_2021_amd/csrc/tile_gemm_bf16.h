@@ -77,15 +77,19 @@ __device__ __forceinline__ void store_chunk16(const f32x4 (&r)[TileCfg16<NB>::LD
 // columns of one row per register quad, so the epilogue stores 8 (bf16) / 16 (f32) bytes per lane.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// OUT: 0 f32, 1 bf16, 2 split bf16 -- three planes of ldc columns in rows of 3 ldc: [hi | hi | lo], hi = bf16(x), lo = bf16(x - hi):
-// the A operand of a next layer whose weights are stacked [hi ; lo ; hi] along K, so that ONE bf16 GEMM of three times the
-// depth forms  hi hi' + hi lo' + lo hi'  -- the product to ~2^-17 relative (only lo lo' is dropped), f32-grade results
-// from the bf16 matrix pipes (nnmpc_nn_create, use_bf16 = 2).
+// OUT: 0 f32, 1 bf16, 2 split bf16 -- two planes of ldc columns in rows of 2 ldc: [hi | lo], hi = bf16(x), lo = bf16(x - hi).
+// Such rows are the A operand of a next layer run with nk0 > 0 (the planes have nk0 K-chunks each): its K loop walks the planes
+// hi, hi, lo against weights stacked [hi ; lo ; hi], so that ONE bf16 GEMM of three times the depth forms
+// hi hi' + hi lo' + lo hi' -- the product to ~2^-17 relative (only lo lo' is dropped): f32-grade results from the bf16 matrix
+// pipes (nnmpc_nn_create, use_bf16 = 2).
+__device__ __forceinline__ int split_chunk(int c, int nk0) {   // K-chunk c of [hi, hi, lo] -> chunk of the two-plane row [hi | lo]
+  return nk0 == 0 ? c : (c < nk0 ? c : c - nk0);
+}
 template <int NB, bool RELU, bool BIAS, int OUT>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, int ldc,
                                                       const bf16raw* __restrict__ A, size_t lda,
                                                       const bf16raw* __restrict__ B, size_t ldb, int K,
-                                                      const float* __restrict__ bias, int ntm, int ntn) {
+                                                      const float* __restrict__ bias, int ntm, int ntn, int nk0 = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   bf16raw* lds = reinterpret_cast<bf16raw*>(lds_raw);
   using Cf = TileCfg16<NB>;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, int
     store_chunk16<NB>(rb, sB, tid);
     __syncthreads();
     if (kc + 1 < nk) {
-      load_chunk16<NB>(ra, Ag + (kc + 1) * KC16, lda, tid);
+      load_chunk16<NB>(ra, Ag + split_chunk(kc + 1, nk0) * KC16, lda, tid);
       load_chunk16<NB>(rb, Bg + (kc + 1) * KC16, ldb, tid);
     }
     if (live) mma_chunk16<NB>(acc, sA, sB, wr, wc, lane);
@@ -142,14 +146,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_k(void* __restrict__ Cv, int
             float x = acc[mi][mj][4 * j + e] + bv[e];
             v[e] = RELU ? (x > 0.f ? x : 0.f) : x;
           }
-          const size_t o = (size_t)(row0 + mi * 32) * (OUT == 2 ? 3 * ldc : ldc) + col;
+          const size_t o = (size_t)(row0 + mi * 32) * (OUT == 2 ? 2 * ldc : ldc) + col;
           if (OUT == 2) {
             const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             const bf16x4 l = {(__bf16)(v[0] - (float)h[0]), (__bf16)(v[1] - (float)h[1]), (__bf16)(v[2] - (float)h[2]), (__bf16)(v[3] - (float)h[3])};
             __bf16* cp = reinterpret_cast<__bf16*>(Cv) + o;
             *reinterpret_cast<bf16x4*>(cp) = h;
-            *reinterpret_cast<bf16x4*>(cp + ldc) = h;
-            *reinterpret_cast<bf16x4*>(cp + 2 * ldc) = l;
+            *reinterpret_cast<bf16x4*>(cp + ldc) = l;
           } else if (OUT == 1) {
             bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(Cv) + o) = h;
@@ -179,7 +182,8 @@ constexpr int WBM = 256, WBN = 208, WNT = 7;               // WNT: column tiles 
 constexpr int W_STAGE = (WBM + 256) * 64;                  // bf16 elements per stage (A, then B padded to 256 rows: staging writes need no branch)
 constexpr int W_LDS_BYTES = 2 * W_STAGE * 2 + 1024;        // two stages + the workgroup's bias values
 
-// SPLIT: the output goes out as the three planes [hi | hi | lo] of gemm_nt_bf16_k's OUT = 2 (rows of 3 ldc elements).
+// SPLIT: input AND output rows are the two planes [hi | lo] of gemm_nt_bf16_k's OUT = 2 (A: rows of lda = 2 K / 3 elements, the K
+// loop walks hi, hi, lo; C: rows of 2 ldc elements).
 template <bool RELU, bool BIAS, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ C, int ldc,
                                                            const bf16raw* __restrict__ A, size_t lda,
@@ -281,8 +285,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
   const int S = np * nk;                                    // steps = panels x chunks
   const int panelA = (int)(WBM * lda * 2), offB = tn * (int)(WBN * ldb * 2);
   int ca = 0, pa = 0, oa = p0 * panelA, cb = 0;             // load cursors: chunk / panel / panel byte offset of the next A load; chunk of the next B load
+  const int nk0 = SPLIT ? nk / 3 : 0;                       // chunks per plane of a split input row
   auto nextA = [&](u32x4 (&ra)[4]) {
-    gloadA(ra, oa + ca * 128);
+    gloadA(ra, oa + split_chunk(ca, nk0) * 128);
     if (++ca == nk) { ca = 0; if (pa + 1 < np) { ++pa; oa += pstride * panelA; } }
   };
   auto nextB = [&] {
@@ -313,13 +318,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
   auto epilogue = [&](int pc, bf16raw* stage) {
     unsigned char* er = reinterpret_cast<unsigned char*>(stage) + wave * (32 * ESTRIDE);
     const int m0 = (p0 + pstride * pc) * WBM;
-    const size_t ldr = SPLIT ? (size_t)3 * ldc : (size_t)ldc;   // elements per row of C
+    const size_t ldr = SPLIT ? (size_t)2 * ldc : (size_t)ldc;   // elements per row of C
     __bf16* Cw = C + (size_t)(m0 + 64 * wm) * ldr + n0 + 16 * WNT * wn;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll 1
-      for (int plane = 0; plane < (SPLIT ? 2 : 1); ++plane) { // 0: hi (bf16 of the value) -> columns [0, ldc) and, SPLIT, [ldc, 2 ldc);
-#pragma unroll                                              //    1 (SPLIT): lo (bf16 of value - hi) -> [2 ldc, 3 ldc)
+      for (int plane = 0; plane < (SPLIT ? 2 : 1); ++plane) { // 0: hi (bf16 of the value) -> columns [0, ldc);
+#pragma unroll                                              // 1 (SPLIT): lo (bf16 of value - hi) -> [ldc, 2 ldc)
         for (int nt = 0; nt < WNT; ++nt) {
           if (nt < WNT - 1 || wn == 0) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + 16 * (WNT * wn + nt) + 4 * g);
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
             }
           }
         }
-        __bf16* Cp = Cw + (SPLIT && plane == 1 ? 2 * (size_t)ldc : 0);
+        __bf16* Cp = Cw + (SPLIT && plane == 1 ? (size_t)ldc : 0);
         int row = lane / npc, c = lane - row * npc;          // piece q = lane + 64 i -> (row, c) = (q / npc, q % npc)
         const int dr = 64 / npc, dc = 64 % npc;
 #pragma unroll 1
@@ -352,10 +357,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_k(__bf16* __restrict__ 
           const bool in0 = ok0 && n0 + 16 * WNT * wn + 8 * c < ldc, in1 = ok1 && n0 + 16 * WNT * wn + 8 * c1 < ldc;
           if (in0) *reinterpret_cast<u32x4*>(Cp + (size_t)(32 * h + row) * ldr + 8 * c) = v0;
           if (in1) *reinterpret_cast<u32x4*>(Cp + (size_t)(32 * h + row1) * ldr + 8 * c1) = v1;
-          if (SPLIT && plane == 0) {                          // the hi plane a second time
-            if (in0) *reinterpret_cast<u32x4*>(Cp + ldc + (size_t)(32 * h + row) * ldr + 8 * c) = v0;
-            if (in1) *reinterpret_cast<u32x4*>(Cp + ldc + (size_t)(32 * h + row1) * ldr + 8 * c1) = v1;
-          }
           row = row1 + dr; c = c1 + dc;
           if (c >= npc) { c -= npc; ++row; }
         }
