@@ -112,6 +112,7 @@ typedef struct {
   double asm_lambda64_ms;    /* ... and of the fp64 instance (asm_lambda_reg_k) */
   double asm_lambda32_flops; /* the part of asm_lambda_flops solved in f32 rounds (price it against the f32 MFMA peak) */
   int64_t asm_lambda32_launches, asm_lambda64_launches;
+  int64_t asm_far_passes;    /* full-width passes that ran in the far-field form (nnmpc_qp_set_farfield) */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);
@@ -161,6 +162,22 @@ int nnmpc_qp_solve_batch_ex(nnmpc_qp* h, int32_t B, const double* x0, const doub
  * close to call are re-checked against P itself in fp64, and problems the pass cannot finish go
  * through the PDIP path. */
 int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc);
+
+/* Far-field form of the full-width pass.  A problem whose active set lies inside the leading W variables (the column
+ * window of the active-set rounds) has, for the variables beyond,
+ *     x[W:] = M [x0 ; lam[0:W]],      M = [Kunc[W:] | -Hinv[W:, 0:W]]      ((n - W) x (n_aug + W)),
+ * and M has numerical rank ~Nx: beyond the last active bound the optimum of the reference's condensed problem
+ * (lib/linearMPC.py:430-474, terminal penalty = the DARE solution, :356) follows the unconstrained recursion, a linear
+ * function of the state at the window's end.  With M = U [Vx | Vl] (r columns; e.g. a truncated SVD, U = U_r S_r) the pass
+ * costs 2 r (n_aug + W + n - W) instead of 2 (n_aug + W)(n - W) flops per problem.  U: (n - W) x r, Vx: r x n_aug,
+ * Vl: r x W, host, row-major.  The library verifies the factors on the device (max |U [Vx | Vl] - M|, refused above 1e-9,
+ * and that bound enters every certificate that rests on them).  W must be a multiple of 128 below n; several windows
+ * may be set.  First-move calls (NNMPC_OUT_FIRST_MOVE) additionally skip the 128-column tiles that
+ * |x_j| <= |U_j| |T_p| <= min_k min(ub_k, -lb_k) certifies feasible -- nothing out there is delivered. */
+int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, const double* Vx, const double* Vl);
+/* *W = window of the last full-width pass that had to run in the dense form for want of such factors (0: none); the
+ * host wrapper factors M for it and calls nnmpc_qp_set_farfield (one-time setup, like the inverse itself). */
+int nnmpc_qp_farfield_missing(nnmpc_qp* h, int32_t* W);
 
 /* out (B x nu) = u[:, 0:nu] + us for HBM-resident sequences u (B rows of ldu doubles): the absolute first moves, i.e.
  * get_control_sequence's "+ tile(us)" (lib/linearMPC.py:689) restricted to what simulate_offline keeps (:856).

@@ -30,12 +30,12 @@ class QpStats(C.Structure):
                 ("asm_lambda_bytes", C.c_double), ("asm_e1max", C.c_double),
                 ("asm_e2max", C.c_double), ("asm_full_checks", C.c_int64), ("asm_lambda32_ms", C.c_double),
                 ("asm_lambda64_ms", C.c_double), ("asm_lambda32_flops", C.c_double),
-                ("asm_lambda32_launches", C.c_int64), ("asm_lambda64_launches", C.c_int64)]
+                ("asm_lambda32_launches", C.c_int64), ("asm_lambda64_launches", C.c_int64), ("asm_far_passes", C.c_int64)]
 
 
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",
            "nnmpc_qp_solve_batch_warm", "nnmpc_qp_solve_batch_ex", "nnmpc_qp_set_inverse", "nnmpc_qp_dims",
-           "nnmpc_qp_first_moves",
+           "nnmpc_qp_first_moves", "nnmpc_qp_set_farfield", "nnmpc_qp_farfield_missing",
            "nnmpc_qp_set_profiling", "nnmpc_qp_get_stats", "nnmpc_qp_debug_factor_solve",
            "nnmpc_nn_create", "nnmpc_nn_destroy", "nnmpc_nn_forward", "nnmpc_nn_last_ms", "nnmpc_nn_last_hidden_ms",
            "nnmpc_chain_create", "nnmpc_chain_destroy", "nnmpc_chain_run", "nnmpc_chain_reset", "nnmpc_chain_last_ms",
@@ -76,6 +76,10 @@ def load():
     lib.nnmpc_qp_solve_batch_warm.argtypes = [vp, i32, dp, dp, dp, dp, dp, dp, dp, dp, i32]
     lib.nnmpc_qp_set_inverse.restype = i32
     lib.nnmpc_qp_set_inverse.argtypes = [vp, dp, dp]
+    lib.nnmpc_qp_set_farfield.restype = i32
+    lib.nnmpc_qp_set_farfield.argtypes = [vp, i32, i32, dp, dp, dp]
+    lib.nnmpc_qp_farfield_missing.restype = i32
+    lib.nnmpc_qp_farfield_missing.argtypes = [vp, C.POINTER(i32)]
     lib.nnmpc_qp_set_profiling.restype = i32
     lib.nnmpc_qp_set_profiling.argtypes = [vp, i32]
     lib.nnmpc_qp_get_stats.restype = i32

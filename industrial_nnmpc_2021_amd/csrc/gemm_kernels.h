@@ -5,6 +5,7 @@
 // f64: MFMA 16x16x4 f64, 64 x 64 tile (PCG residuals P v and q = tq x0; <1 % of the flops of a solve).
 #pragma once
 #include "tile_gemm.h"
+#include "gemm64.h"
 
 namespace nnmpc {
 
@@ -89,8 +90,6 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kdyn_k(float* __restrict__ C,
 // staged through LDS as [64 rows][16 k] with row stride 18 doubles (conflict-free ds_read_b64:
 // lane (i = l & 15, kq = l >> 4) reads k = 4 s + kq of row i).
 // rowphase (nullable): per-row tag; 64-row blocks in which no row has tag `want` are skipped.
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 static __global__ __launch_bounds__(256) void gemm_nt_f64_k(double* __restrict__ C, size_t ldc,
                                                      const double* __restrict__ A, size_t lda,
                                                      const double* __restrict__ B, size_t ldb,

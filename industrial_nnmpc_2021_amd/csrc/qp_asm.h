@@ -51,6 +51,7 @@ constexpr int ASM_CNT_WKMAX = 27;  // counters[27 + g]: that bound (from the gro
 constexpr int ASM_TAIL_MB = 8;     // asm_tail_k keeps the tiles of sets of up to 128 bounds in LDS
 constexpr int ASM_CNT_TAIL = 35;   // counters[35]: problems handed to asm_tail_k
 constexpr int ASM_CNT_WDONE = 32;  // counters[32 + g]: problems of group g handled by the last asm_wide_k (statistics)
+constexpr int ASM_CNT_FFTILES = 38; // counters[38]: 128 x 128 tiles the far-field pass evaluated in first-move calls (statistics; cumulative over a segment)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
 // ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
@@ -71,8 +72,21 @@ struct AsmDev {
   int max_rounds;
   double bound_tol, stat_tol, pscale;
   double e1max, e2max;             // max |P Kunc + tq|, max |P Pinv - I| (verified once at setup)
-  const double* x0;                // [nseg][ka] padded initial states (for the certificate)
+  const double* x0;                // [nseg][ka] padded initial states (for the certificate; first K segment of the full-width pass)
   int ka;
+  const double* Kunc;              // [np][ka]: x_unc = Kunc x0
+  int Wx;                          // x_unc exists in HBM for the columns [0, Wx) only (Wx = np: all of them); beyond, the full-width
+                                   // pass forms it inside its GEMM (qp_wide.h), the rare consumers below from Kunc and x0
+  // far-field form of the full-width pass (qp_wide.h; nnmpc_qp_set_farfield): x[ffW:] = U (Vx x0 + Vl lam[0:ffW])
+  const double* ffU;               // [np - ffW][ffr]
+  const double* ffVx;              // [ffr][ka]
+  const double* ffVl;              // [ffr][ffW]  (minus sign of the Pinv block included)
+  const double* ffcu;              // [(np - ffW) / 128] bound on |U_j| over all columns at or beyond each 128-column tile
+  int ffr, ffW;                    // padded rank (multiple of 128), the window the factors belong to
+  double* T;                       // [row tiles * 128][ffr]
+  double *tnorm, *tslack;          // [row tiles * 128] |T_p| and min_k min(ub_k, -lb_k) (first-move calls)
+  int ff_skip;                     // first-move call: column tiles certified feasible by |U_j| |T_p| are not evaluated
+  double ff_err;                   // |P|_inf * max |U V' - M| of the factors the last full-width pass used (0: dense form): enters the certificate
   const double* H;                 // [np][np] fp64 inverse Hessian
   const float* H32;                // the same rounded to f32 (operand of the f32 GEMM; the f32 rounds gather S from it: same values as
                                    // rounding the fp64 entries on the fly, half the bytes)
@@ -1400,7 +1414,8 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
   const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
   const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
   const double QI = d.tqmax * X1;                            // >= |q|_inf
-  const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1);
+  // (far-field pass: x beyond the window is off by at most max|U V' - M| (|x0|_1 + |lam|_1), its gradient by |P|_inf times that)
+  const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1) + d.ff_err * (X1 + L1);
   const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
   if (tot == 0 && !sure) {                                   // P itself has to confirm this one: x as a GEMM row
     for (int r = tid; r < d.n; r += 256) {                   // (nothing changed: st still is the set x belongs to)
@@ -1413,7 +1428,13 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
         const double* Hc = d.H + r;
         double a0 = 0.0;
         for (int i = 0; i < m; ++i) a0 += Hc[(size_t)idx[i] * d.np] * wl_lam[i];
-        x = d.xunc[o + r] - a0;
+        double xu;
+        if (r < d.Wx) xu = d.xunc[o + r];
+        else {                                               // x_unc beyond the columns kept in HBM: Kunc[r] . x0
+          xu = 0.0;
+          for (int k = 0; k < d.ka; ++k) xu += d.Kunc[(size_t)r * d.ka + k] * d.x0[(size_t)p * d.ka + k];
+        }
+        x = xu - a0;
       }
       d.x[o + r] = x;
     }

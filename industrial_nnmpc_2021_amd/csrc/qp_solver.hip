@@ -673,6 +673,12 @@ struct nnmpc_qp {
   double tqmax;         // max |tq| entry
   int asm_pool;
   double asm_e1max, asm_e2max;
+  // far-field factorisations of the full-width pass (nnmpc_qp_set_farfield), one per window
+  struct Far { int W, r, rp; double *U, *Vx, *Vl, *cu; double efar; };
+  std::vector<Far> far;
+  int far_missing = 0;      // window of the last full-width pass that ran in the dense form for want of factors
+  double p_inf = 0.0;       // max row sum of |P|
+  double *asm_tnorm = nullptr, *asm_tslack = nullptr;
   double* asm_work;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
   double* x0_64;        // [seg_max][ka]
@@ -782,11 +788,12 @@ void gemm32(nnmpc_qp* h, float* C, size_t ldc, const float* A, size_t lda, const
 }
 void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, const double* B,
             size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0,
-            const int* kdyn = nullptr, const int* mdyn = nullptr, bool kblocks = false) {
-  // kblocks: kdyn holds one bound per 64 rows of A (else one for the launch)
-  if (M % 128 == 0 && N % 128 == 0) {
-    hipLaunchKernelGGL(gemm_nt_f64_128_k, dim3(N / 128, M / 128), dim3(256), GEMM64_128_LDS, h->stream, C, ldc, A, lda, B, ldb, K,
-                       rowphase, want, kdyn, mdyn, kblocks ? 2 : 0);
+            const int* kdyn = nullptr, const int* mdyn = nullptr, bool kblocks = false, const int* rowmap = nullptr) {
+  // kblocks: kdyn holds one bound per 64 rows of A (else one for the launch); rowmap: gather / scatter of the rows (gemm64.h)
+  if (M % 128 == 0 && N % 128 == 0 && K % G64_KC == 0) {
+    const int ntm = M / 128, ntn = N / 128;
+    hipLaunchKernelGGL(gemm_nt_f64_t128_k, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, h->stream, C, ldc, A, lda, B, ldb, K, ntm, ntn,
+                       rowphase, want, kdyn, kblocks ? 2 : 0, mdyn, rowmap);
     return;
   }
   dim3 grid(N / 64, M / 64);
@@ -917,12 +924,26 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   hipStream_t s = h->stream;
   const int segp = ((nprob + 127) / 128) * 128;
   hipLaunchKernelGGL(pad_x0_k, dim3(512), dim3(256), 0, s, h->x0_64, h->x0_32, x0_dev, nprob, h->n_aug, h->ka, segp);
-  // x_unc = Kunc x0 for the whole segment; q = tq x0 is only formed for the rows that need the full check with P
+  static const bool no_fuse = getenv("NNMPC_NO_FUSED_WIDE") != nullptr;   // diagnostics: A/B of the fused epilogue
+  static const bool no_lazy = getenv("NNMPC_NO_LAZY_XUNC") != nullptr;    // diagnostics: x_unc for all columns up front (round 2)
+  const bool tail_only = h->opts.asm_tail_batch >= 0 && nprob <= std::min(std::min(h->asm_pool, 256), h->opts.asm_tail_batch ? h->opts.asm_tail_batch : 256);
+  // x_unc = Kunc x0 -- for the leading columns only (the window the first sets are drawn from; extended should a round's
+  // window outgrow it): beyond them x_unc is one K segment of the full-width pass's GEMM (qp_wide.h).  Calls that go to
+  // the device tail from the start, and shapes the fused kernel's tiles do not fit, form all of it.  q = tq x0 is only
+  // formed for the rows that need the full check with P.
+  const bool lazy = h->np % 128 == 0 && !no_fuse && !no_lazy && !tail_only && (uint64_t)h->seg_max * h->ka * 8 < (1ull << 32);
+  int Wx = h->np;
+  if (lazy) Wx = std::min(h->np, guess_dev ? 512 : ((std::min(h->n, std::max(512, ((h->n / 4 + 127) / 128) * 128)) + 127) / 128) * 128);
   {
-    EvScope es(h, 5, 2.0 * h->np * (double)h->ka * nprob);
-    gemm64(h, h->asm_xunc, h->np, h->x0_64, h->ka, h->Kunc64, h->ka, segp, h->np, h->ka);
+    EvScope es(h, 5, 2.0 * Wx * (double)h->ka * nprob);
+    gemm64(h, h->asm_xunc, h->np, h->x0_64, h->ka, h->Kunc64, h->ka, segp, Wx, h->ka);
   }
   AsmDev a;
+  a.Kunc = h->Kunc64; a.Wx = Wx;
+  a.ffU = a.ffVx = a.ffVl = a.ffcu = nullptr; a.ffr = a.ffW = 0; a.T = h->asm_xhw; a.tnorm = h->asm_tnorm; a.tslack = h->asm_tslack;
+  a.ff_skip = 0; a.ff_err = 0.0;
+  static const bool no_far = getenv("NNMPC_NO_FARFIELD") != nullptr;      // diagnostics: dense form of the full-width pass (A/B)
+  int wide_far_rp = 0, fft_prev = 0;                      // the last full-width pass ran in the far-field form with this padded rank
   a.n = h->n; a.np = h->np; a.nu = h->nu; a.nseg = nprob;
   a.max_active = h->opts.asm_max_active; a.max_rounds = h->opts.asm_max_rounds;
   a.bound_tol = h->opts.bound_tol; a.stat_tol = 1e-8; a.pscale = h->pscale;
@@ -945,7 +966,6 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   int prev_run = 0;                                     // upper bound of the problems awaiting the full-width check
   int kprev = 0, wide_cols = 0, kref_prev = 0, fused_c0 = -1;
   HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
-  const bool tail_only = h->opts.asm_tail_batch >= 0 && nprob <= std::min(std::min(h->asm_pool, 256), h->opts.asm_tail_batch ? h->opts.asm_tail_batch : 256);
   if (tail_only) {
     // A call of at most 256 problems -- the lock-step chains of a task, a controller's single QP -- is finished on the
     // device from the start (asm_tail_k: count -> fp64 solve -> x over all columns -> exchange rule, one workgroup per
@@ -975,15 +995,33 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         // (a.W is still last round's window: those columns are in that round's XH rows already); one launch per
         // k-group region: its rows share a last active bound
         const int c0 = (a.W < h->np && (h->np - a.W) % 128 == 0) ? a.W : 0;
-        static const bool no_fuse = getenv("NNMPC_NO_FUSED_WIDE") != nullptr;   // diagnostics: A/B of the fused epilogue
         fused_c0 = ((h->np - c0) % 128 == 0 && !no_fuse) ? c0 : -1;     // the fused kernel's 128-column tiles fit: check in the GEMM's epilogue
-        for (int g = 0; g < ASM_NKG; ++g) {
-          const size_t r0 = (size_t)g * a.wcap * h->np;
-          if (fused_c0 >= 0)
-            hipLaunchKernelGGL(asm_wide_gemm_k, dim3((h->np - c0) / 128, (prev_run + 127) / 128), dim3(256), GEMM64_128_LDS, s, a, g, c0);
-          else
+        const int ntm = (prev_run + 127) / 128 + (ASM_NKG - 1), ntn = (h->np - c0) / 128;   // row tiles of all k-groups in ONE launch
+        const nnmpc_qp::Far* ff = nullptr;
+        if (lazy && fused_c0 > 0 && !no_far) {
+          for (const auto& f : h->far) if (f.W == c0) ff = &f;
+          if (!ff) h->far_missing = c0;                  // (the host wrapper may add the factors for this window: nnmpc_qp_farfield_missing)
+        }
+        a.ff_err = 0.0; a.ff_skip = 0; wide_far_rp = 0;
+        if (ff) {
+          // far-field form: T = [x0 | lamw] V, x[c0:] = T U'; first-move calls skip the column tiles |U_j| |T_p| certifies
+          a.ffU = ff->U; a.ffVx = ff->Vx; a.ffVl = ff->Vl; a.ffcu = ff->cu; a.ffr = ff->rp; a.ffW = ff->W;
+          a.ff_err = h->p_inf * ff->efar;
+          a.ff_skip = h->nout <= c0 && h->nout < h->n;
+          wide_far_rp = ff->rp;
+          hipLaunchKernelGGL(asm_wide_t_k, dim3(g64_grid(ntm, ff->rp / 128)), dim3(256), G64_LDS, s, a, ntm, ff->rp / 128);
+          if (a.ff_skip) hipLaunchKernelGGL(asm_wide_tnorm_k, dim3((ntm * 128 + 3) / 4), dim3(256), 0, s, a, ntm);
+          hipLaunchKernelGGL(asm_wide_gemm_k<WIDE_FAR>, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, s, a, c0, ntm, ntn);
+        } else if (fused_c0 >= 0 && lazy) {              // (lazy: c0 = W >= the first window -- never 0 -- and x_unc exists up to Wx >= W)
+          hipLaunchKernelGGL(asm_wide_gemm_k<WIDE_LAZY>, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, s, a, c0, ntm, ntn);
+        } else if (fused_c0 >= 0) {
+          hipLaunchKernelGGL(asm_wide_gemm_k<WIDE_XUNC>, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, s, a, c0, ntm, ntn);
+        } else {
+          for (int g = 0; g < ASM_NKG; ++g) {
+            const size_t r0 = (size_t)g * a.wcap * h->np;
             gemm64(h, h->asm_xhw + r0 + c0, h->np, h->asm_lamw + r0, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_run + 127) / 128) * 128,
                    h->np - c0, h->np, nullptr, 0, h->asm_counters + ASM_CNT_WKMAX + g, h->asm_counters + ASM_CNT_WIDEG + g);
+          }
         }
         wide_cols = h->np - c0;
       }
@@ -1006,7 +1044,19 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         double ksum = 0.0;                                // (bounds of the groups as asm_bins_b_k set them a round earlier)
         for (int g = 0; g < ASM_NKG; ++g)
           ksum += (double)cnt[ASM_CNT_WDONE + g] * (1 + (g == ASM_NKG - 1 ? kprev : std::min(kprev, asm_kgroup_bound_of(g, kref_prev, h->nu))));
-        h->stats.asm_gemm_flops += 2.0 * wide_cols * ksum;
+        double nw = 0.0;
+        for (int g = 0; g < ASM_NKG; ++g) nw += cnt[ASM_CNT_WDONE + g];
+        if (wide_far_rp) {
+          // far-field form: T = z V (k = n_aug + own k-range) and x = T U' (k = rp) -- over all columns, or (first-move calls)
+          // over the 128 x 128 tiles the certificate did not cover (device count)
+          const double tiles = cnt[ASM_CNT_FFTILES] - fft_prev;
+          h->stats.asm_gemm_flops += 2.0 * wide_far_rp * (ksum + nw * h->ka) +
+                                     (a.ff_skip ? 2.0 * wide_far_rp * 128.0 * 128.0 * tiles : 2.0 * wide_far_rp * (double)wide_cols * nw);
+          h->stats.asm_far_passes += 1;
+        } else {
+          h->stats.asm_gemm_flops += 2.0 * wide_cols * (ksum + (lazy ? nw * h->ka : 0.0));   // (lazy: x_unc beyond the window is part of that pass)
+        }
+        fft_prev = cnt[ASM_CNT_FFTILES];
     }
     kprev = cnt[3];
     {
@@ -1027,6 +1077,12 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       // problems per call the rounds 7..12 were launches for a few dozen problems, 5 % of the step)
       EvScope es(h, 4, 0.0);
       hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
+      if (Wx < h->np) {
+        // the tail evaluates all columns of its problems straight from Pinv: their x_unc rows beyond Wx, gathered by problem
+        gemm64(h, h->asm_xunc + Wx, h->np, h->x0_64, h->ka, h->Kunc64 + (size_t)Wx * h->ka, h->ka, ((nrun + 127) / 128) * 128, h->np - Wx, h->ka,
+               nullptr, 0, nullptr, h->asm_counters + ASM_CNT_TAIL, false, h->asm_biglist);
+        a.Wx = h->np;                                    // (for these problems)
+      }
       const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_AREA) * 8 + ((h->n + 15) / 16) * 16 + ASM_TAIL_EXTRA;
       hipLaunchKernelGGL(asm_tail_k, dim3(nrun), dim3(256), lds_tail, s, a, h->asm_tail_budget);
       HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1057,6 +1113,12 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     // column window of this round: past the last active bound of any running problem plus one stage; a
     // problem that settles inside it gets one full-width pass (asm_wide_k) at the start of the next round
     a.W = std::min(h->np, ((cnt[3] + 1 + h->nu + 127) / 128) * 128);
+    if (a.W > Wx) {
+      // a set reaches beyond the columns x_unc was formed for (a bound the full-width pass found violated out there): extend
+      EvScope es(h, 5, 2.0 * (a.W - Wx) * (double)h->ka * nprob);
+      gemm64(h, h->asm_xunc + Wx, h->np, h->x0_64, h->ka, h->Kunc64 + (size_t)Wx * h->ka, h->ka, segp, a.W - Wx, h->ka);
+      Wx = a.W; a.Wx = Wx;
+    }
     {
       EvScope es(h, 4, 0.0);
       // one wave per problem, S in registers: size classes 0..5 (<= 144 bounds) in one launch, four problems per
@@ -1261,8 +1323,11 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_tail_k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_reg32b_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_REG32B_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_lambda_tile32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_TILE32_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_128_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_128_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f64_t128_k, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k<WIDE_XUNC>, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k<WIDE_LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k<WIDE_FAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_t_k, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_kdyn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
@@ -1310,6 +1375,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka); A_(h->H32, (size_t)np * np);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G); A_(h->asm_wflag, G);
+  A_(h->asm_tnorm, G + 128 * (ASM_NKG + 1)); A_(h->asm_tslack, G + 128 * (ASM_NKG + 1));
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 2) * G);
   A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 3 * G);
@@ -1343,6 +1409,11 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     }
   }
   d.pscale = h->pscale;
+  for (int r = 0; r < n; ++r) {
+    double rs = 0.0;
+    for (int c = 0; c < n; ++c) rs += std::fabs(p64[(size_t)r * np + c]);
+    h->p_inf = std::max(h->p_inf, rs);
+  }
   d.delta = 16.f * 5.96e-8f * pdmax;   // keeps the f32 Cholesky positive for cond(P) >~ 1e7
   d.pdiag = h->pdiag;
   for (int i = 0; i < h->T; ++i)
@@ -1448,6 +1519,73 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
     }
   }
   h->have_inverse = true;
+  return NNMPC_OK;
+}
+
+int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, const double* Vx, const double* Vl) {
+  if (!h || !U || !Vx || !Vl || r <= 0) { set_error("nnmpc_qp_set_farfield: bad arguments"); return NNMPC_EINVAL; }
+  if (!h->have_inverse) { set_error("nnmpc_qp_set_farfield: needs nnmpc_qp_set_inverse first"); return NNMPC_EINVAL; }
+  HIPCHK(hipSetDevice(h->device));
+  const int n = h->n, np = h->np, ka = h->ka, n_aug = h->n_aug;
+  const int rp = ((r + 127) / 128) * 128;
+  if (W <= 0 || W % 128 != 0 || W >= n || np % 128 != 0) { set_error("nnmpc_qp_set_farfield: W = %d must be a multiple of 128 below n = %d (padded %d)", W, n, np); return NNMPC_EINVAL; }
+  if ((uint64_t)(h->seg_max + 128 * (ASM_NKG + 1)) * rp > (uint64_t)ASM_NKG * h->seg_max * np) { set_error("nnmpc_qp_set_farfield: rank %d too large for the workspace", r); return NNMPC_EINVAL; }
+  const int nf = np - W;                                  // rows of the far block (padding rows: zero)
+  std::vector<double> u((size_t)nf * rp, 0.0), vx((size_t)rp * ka, 0.0), vl((size_t)rp * W, 0.0), cu(nf / 128, 0.0);
+  for (int j = 0; j < n - W; ++j)
+    for (int i = 0; i < r; ++i) u[(size_t)j * rp + i] = U[(size_t)j * r + i];
+  for (int i = 0; i < r; ++i) {
+    for (int k = 0; k < n_aug; ++k) vx[(size_t)i * ka + k] = Vx[(size_t)i * n_aug + k];
+    for (int k = 0; k < W; ++k) vl[(size_t)i * W + k] = Vl[(size_t)i * W + k];
+  }
+  // |U_j| (2-norm of the row, rounded up), then its maximum over all columns at or beyond each 128-column tile
+  {
+    double run = 0.0;
+    for (int t = nf / 128 - 1; t >= 0; --t) {
+      for (int j = 128 * t; j < 128 * (t + 1); ++j) {
+        double s2 = 0.0;
+        for (int i = 0; i < rp; ++i) s2 += u[(size_t)j * rp + i] * u[(size_t)j * rp + i];
+        run = std::max(run, std::sqrt(s2) * (1.0 + 1e-12));
+      }
+      cu[t] = run;
+    }
+  }
+  nnmpc_qp::Far f;
+  f.W = W; f.r = r; f.rp = rp; f.U = f.Vx = f.Vl = f.cu = nullptr; f.efar = 0.0;
+  int rc = 0;
+  if (!rc) rc = dev_alloc(h, &f.U, u.size());
+  if (!rc) rc = dev_alloc(h, &f.Vx, vx.size());
+  if (!rc) rc = dev_alloc(h, &f.Vl, vl.size());
+  if (!rc) rc = dev_alloc(h, &f.cu, cu.size());
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(f.U, u.data(), u.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(f.Vx, vx.data(), vx.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(f.Vl, vl.data(), vl.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(f.cu, cu.data(), cu.size() * 8, hipMemcpyHostToDevice));
+  // ---- verify on the device copies the passes will use: max |U [Vx | Vl] - [Kunc[W:] | -Pinv[W:, 0:W]]|
+  {
+    unsigned long long* em = nullptr;
+    HIPCHK(hipMalloc((void**)&em, 8));
+    HIPCHK(hipMemset(em, 0, 8));
+    hipLaunchKernelGGL(far_verify_k, dim3(nf), dim3(256), rp * sizeof(double), h->stream, f.U, f.Vx, f.Vl, h->Kunc64, h->H64, W, rp, ka, np, em);
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, em, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(stream_sync(h->stream));
+    hipFree(em);
+    double e;
+    memcpy(&e, &bits, 8);
+    f.efar = e;
+    if (!(e < 1e-9)) { set_error("nnmpc_qp_set_farfield: max |U V' - M| = %.3e: the factors are not usable", e); return NNMPC_EINVAL; }
+  }
+  for (auto& g : h->far) if (g.W == W) { g = f; if (h->far_missing == W) h->far_missing = 0; return NNMPC_OK; }   // (replaces; the old copies stay allocated until destroy)
+  h->far.push_back(f);
+  if (h->far_missing == W) h->far_missing = 0;
+  return NNMPC_OK;
+}
+
+int nnmpc_qp_farfield_missing(nnmpc_qp* h, int32_t* W) {
+  if (!h || !W) { set_error("nnmpc_qp_farfield_missing: bad arguments"); return NNMPC_EINVAL; }
+  *W = h->far_missing;
   return NNMPC_OK;
 }
 

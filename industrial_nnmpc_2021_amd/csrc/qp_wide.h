@@ -1,79 +1,51 @@
-// Full-width pass of the active-set path with the check in the GEMM's epilogue (gfx950).
+// Full-width pass of the active-set path: fp64 GEMMs with the check in the epilogue (gfx950).
 //
-// A problem that settles inside the column window gets ONE pass over the columns beyond it: x = x_unc - lamw * Pinv there,
-// feasibility of the free variables, u written out.  Separate kernels made that  GEMM -> XHW (8 B per element written),
-// asm_wide_k (XHW and x_unc read back, u written: 24 B)  -- HBM-bound bookkeeping next to an MFMA-bound GEMM.  Here the
-// 128 x 128 fp64 tile of gemm_nt_f64_128_k keeps its product in the accumulators and its epilogue does the check: x_unc and the
-// bound states come in (9 B per element), u goes out (8 B), a violated bound changes state in place and raises the
-// problem's flag; asm_wide_k is left with the columns inside the window, the multiplier statistics and the decision.
+// A problem that settles inside the column window [0, W) gets ONE pass over the columns beyond it:
+//     x[W:] = x_unc[W:] - Pinv[W:, A] lam  =  M z,    M = [Kunc[W:] | -Pinv[W:, 0:W]],   z = [x0 ; lam[0:W]]
+// feasibility of the free variables there, u written out; asm_wide_k is left with the columns inside the window, the
+// multiplier statistics and the decision.  Three forms of the product, newest first:
+//
+//  * FAR FIELD (round 3; nnmpc_qp_set_farfield).  Beyond the last active bound the optimum follows the unconstrained
+//    recursion of the terminal-cost LQ problem, so everything out there is a linear function of the (augmented) state at
+//    the window's end: M has numerical rank ~Nx (CDU: 252 of 796 columns, the 253rd singular value is 4e-15 of the first).
+//    With the one-time factorisation  M = U V'  (host, fp64 SVD, verified on the device: max |U V' - M| enters the
+//    certificate)
+//        T = [x0 | lam] V            asm_wide_t_k       rows x rp,    k = n_aug + own k-range
+//        x[W:] = T U'                asm_wide_gemm_k<FAR>             k = rp = 256
+//    2.6 x fewer flops than the dense product at the CDU size -- the same numbers to rounding.
+//    First-move calls (NNMPC_OUT_FIRST_MOVE: nothing beyond the window is delivered, only checked) skip every 128-column
+//    tile that Cauchy-Schwarz certifies:  |x_j| <= |U_j| |T_p| <= min(ub, -lb)  for all rows of the tile and all columns at or
+//    beyond it (|U_j| decays geometrically along the horizon: CDU, W = 512: all but the first ~6 of 31 tiles).
+//  * LAZY (round 3): one GEMM whose K loop has two segments (gemm64.h), x0 against Kunc and the multiplier row against
+//    Pinv, subtracted: x_unc beyond the window never exists in HBM.
+//  * round 2: x_unc for all columns up front, the tile of lamw Pinv in the accumulators, x_unc loaded in the epilogue.
 #pragma once
-#include "gemm_kernels.h"
+#include "gemm64.h"
 #include "qp_asm.h"
 
 namespace nnmpc {
 
-// rows: the problems of k-group g awaiting the check (row w of region g of LAMW -> problem wlist[g * wcap + w]);
-// columns: c0 + 128 blockIdx.x ...; k-range: the group's last possible active bound (counters[ASM_CNT_WKMAX + g]).
-static __global__ __launch_bounds__(256, 2) void asm_wide_gemm_k(AsmDev d, int g, int c0) {
-  constexpr int LD = 18, TS = 128 * LD;
-  extern __shared__ __attribute__((aligned(16))) double sm128[];   // [2][A 128 x LD | B 128 x LD]
-  const int cntg = d.counters[ASM_CNT_WIDEG + g];
-  const int m0 = blockIdx.y * 128, n0 = c0 + blockIdx.x * 128;
-  if (m0 >= cntg) return;
-  const int K = min(d.np, ((d.counters[ASM_CNT_WKMAX + g] + 16) / 16) * 16);
+enum { WIDE_XUNC = 0, WIDE_LAZY = 1, WIDE_FAR = 2 };
+
+// Row tiles of ONE launch over all k-groups: tile tm -> (group, first row in the group's region, rows of the group).
+struct WideTile { int g, m0, cnt; };
+__device__ __forceinline__ bool wide_tile_of(const AsmDev& d, int tm, WideTile& t) {
+  int t0 = 0;
+#pragma unroll
+  for (int g = 0; g < ASM_NKG; ++g) {
+    const int c = d.counters[ASM_CNT_WIDEG + g], nt = (c + 127) >> 7;
+    if (tm < t0 + nt) { t.g = g; t.m0 = (tm - t0) * 128; t.cnt = c; return true; }
+    t0 += nt;
+  }
+  return false;
+}
+
+// ---- epilogue shared by the three forms: x, feasibility of the free variables, u out.  All loads of a row are issued
+// unconditionally and together (a branch per element would turn the epilogue into a chain of dependent round trips).
+template <bool XUNC>
+__device__ __forceinline__ void wide_epilogue(const AsmDev& d, const f64x4 (&acc)[4][4], const int* wl, int m0, int cntg, int n0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const size_t lda = d.np, ldb = d.np;
-  f64x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const int lrow0 = tid >> 3, lc = (tid & 7) * 2;           // rows lrow0 + 32 h
-  const double* Ag = d.lamw + ((size_t)g * d.wcap + m0) * lda;
-  const double* Bg = d.H + (size_t)n0 * ldb;
-  f64x2 ra[4], rb[4];
-#pragma unroll
-  for (int h = 0; h < 4; ++h) {
-    ra[h] = *reinterpret_cast<const f64x2*>(Ag + (size_t)(lrow0 + 32 * h) * lda + lc);
-    rb[h] = *reinterpret_cast<const f64x2*>(Bg + (size_t)(lrow0 + 32 * h) * ldb + lc);
-  }
-  const int li = lane & 15, kq = lane >> 4;
-  const int nk = K / 16;
-  for (int kc = 0; kc < nk; ++kc) {
-    double* sA = sm128 + (kc & 1) * 2 * TS;
-    double* sB = sA + TS;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      *reinterpret_cast<f64x2*>(sA + (lrow0 + 32 * h) * LD + lc) = ra[h];
-      *reinterpret_cast<f64x2*>(sB + (lrow0 + 32 * h) * LD + lc) = rb[h];
-    }
-    __syncthreads();
-    if (kc + 1 < nk) {
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        ra[h] = *reinterpret_cast<const f64x2*>(Ag + (size_t)(lrow0 + 32 * h) * lda + (kc + 1) * 16 + lc);
-        rb[h] = *reinterpret_cast<const f64x2*>(Bg + (size_t)(lrow0 + 32 * h) * ldb + (kc + 1) * 16 + lc);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      double a[4], b[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = sA[(wr * 64 + t * 16 + li) * LD + 4 * s + kq];
-        b[t] = sB[(wc * 64 + t * 16 + li) * LD + 4 * s + kq];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  // ---- epilogue: x = x_unc - (lamw Pinv), feasibility of the free variables, u out.  All loads of a row are issued
-  // unconditionally and together (a branch per element would turn the epilogue into a chain of dependent round trips).
-  const int* wl = d.wlist + (size_t)g * d.wcap;
   int colj[4], kj[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -95,21 +67,20 @@ static __global__ __launch_bounds__(256, 2) void asm_wide_gemm_k(AsmDev d, int g
     for (int r = 0; r < 4; ++r) {
       const int p = prow[4 * i + r];
       const int pc = max(p, 0);
-      const size_t o = (size_t)pc * d.np;
       unsigned char* st = d.st + (size_t)pc * d.n;
       int sv[4];
       double xu[4], lbv[4], ubv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         sv[j] = st[colj[j]];
-        xu[j] = d.xunc[o + colj[j]];
+        xu[j] = XUNC ? d.xunc[(size_t)pc * d.np + colj[j]] : 0.0;
         lbv[j] = d.lb[(size_t)pc * d.nu + kj[j]];
         ubv[j] = d.ub[(size_t)pc * d.nu + kj[j]];
       }
       int viol = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const double xf = xu[j] - acc[i][j][r];
+        const double xf = XUNC ? xu[j] - acc[i][j][r] : acc[i][j][r];
         const int ns = sv[j] != 0 ? sv[j] : (xf > ubv[j] + d.bound_tol ? 1 : (xf < lbv[j] - d.bound_tol ? 2 : 0));
         const double x = sv[j] == 0 ? xf : (sv[j] == 1 ? ubv[j] : lbv[j]);
         const bool live = p >= 0 && (colok || n0 + wc * 64 + j * 16 + (lane & 15) < d.n);
@@ -118,6 +89,120 @@ static __global__ __launch_bounds__(256, 2) void asm_wide_gemm_k(AsmDev d, int g
       }
       if (viol) d.wflag[pc] = 1;                                   // (same value from every writer)
     }
+}
+
+// rows: the problems awaiting the check, all k-groups in one launch (row w of region g of LAMW -> problem
+// wlist[g * wcap + w]); columns: c0 + 128 tn ...; k-range of the multiplier segment: the group's last possible active bound
+// (counters[ASM_CNT_WKMAX + g]).  1-D grid of g64_grid(ntm, ntn) workgroups, ntm >= the row tiles of all groups.
+template <int MODE>
+static __global__ __launch_bounds__(256, 2) void asm_wide_gemm_k(AsmDev d, int c0, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) double g64_sm[];
+  __shared__ long long rowoff[128];
+  int tm, tn;
+  if (!g64_tile_of(blockIdx.x, ntm, ntn, tm, tn)) return;
+  WideTile wt;
+  if (!wide_tile_of(d, tm, wt)) return;
+  const int n0 = c0 + tn * 128, tid = threadIdx.x;
+  const int* wl = d.wlist + (size_t)wt.g * d.wcap;
+  f64x4 acc[4][4];
+  g64_zero(acc);
+  if (MODE == WIDE_FAR) {
+    if (d.ff_skip) {
+      // first-move call: nothing in these columns is delivered.  |x_j| <= |U_j| |T_p| (Cauchy-Schwarz); ffcu[tn] bounds |U_j| for
+      // every column at or beyond this tile, tnorm / tslack hold |T_p| (rounded up) and min_k min(ub_k, -lb_k) of the row's problem
+      const int row = tm * 128 + (tid & 127);
+      const int need = tid < 128 && !(d.ffcu[tn] * d.tnorm[row] <= d.tslack[row]);   // (a NaN needs the check)
+      if (!__syncthreads_or(need)) return;
+      if (tid == 0) atomicAdd(&d.counters[ASM_CNT_FFTILES], 1);
+    }
+    const G64Seg st{d.T + (size_t)tm * 128 * d.ffr, (size_t)d.ffr, d.ffU + (size_t)(n0 - c0) * d.ffr, (size_t)d.ffr, d.ffr / G64_KC};
+    const G64Seg s1{d.T, 0, d.ffU, 0, 0};
+    g64_tile<false>(acc, st, s1, g64_sm);
+    wide_epilogue<false>(d, acc, wl, wt.m0, wt.cnt, n0);
+    return;
+  }
+  const int K1 = min(d.np, ((d.counters[ASM_CNT_WKMAX + wt.g] + G64_KC) / G64_KC) * G64_KC);
+  const G64Seg sl{d.lamw + ((size_t)wt.g * d.wcap + wt.m0) * d.np, (size_t)d.np, d.H + (size_t)n0 * d.np, (size_t)d.np, K1 / G64_KC};
+  if (MODE == WIDE_LAZY) {                                   // x0 rows of the tile's problems (rows beyond the count: row 0, never stored)
+    if (tid < 128) rowoff[tid] = (long long)(wt.m0 + tid < wt.cnt ? wl[wt.m0 + tid] : 0) * (long long)d.ka;
+    __syncthreads();
+    const G64Seg sx{d.x0, (size_t)d.ka, d.Kunc + (size_t)n0 * d.ka, (size_t)d.ka, d.ka / G64_KC};
+    g64_tile<true>(acc, sx, sl, g64_sm, rowoff);             // acc = x0 Kunc' - lamw Pinv'
+    wide_epilogue<false>(d, acc, wl, wt.m0, wt.cnt, n0);
+  } else {
+    const G64Seg s1{d.lamw, 0, d.H, 0, 0};
+    g64_tile<false>(acc, sl, s1, g64_sm);                    // acc = lamw Pinv'
+    wide_epilogue<true>(d, acc, wl, wt.m0, wt.cnt, n0);
+  }
+}
+
+// T = [x0 | lamw] [Vx | Vl]'  for all rows awaiting the check; row tile tm of the launch -> rows 128 tm .. of T.
+static __global__ __launch_bounds__(256, 2) void asm_wide_t_k(AsmDev d, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) double g64_sm[];
+  __shared__ long long rowoff[128];
+  int tm, tn;
+  if (!g64_tile_of(blockIdx.x, ntm, ntn, tm, tn)) return;
+  WideTile wt;
+  if (!wide_tile_of(d, tm, wt)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, n0 = tn * 128;
+  const int* wl = d.wlist + (size_t)wt.g * d.wcap;
+  const int K1 = min(d.ffW, ((d.counters[ASM_CNT_WKMAX + wt.g] + G64_KC) / G64_KC) * G64_KC);   // (Vl has ffW columns)
+  if (tid < 128) rowoff[tid] = (long long)(wt.m0 + tid < wt.cnt ? wl[wt.m0 + tid] : 0) * (long long)d.ka;
+  __syncthreads();
+  f64x4 acc[4][4];
+  g64_zero(acc);
+  const G64Seg sx{d.x0, (size_t)d.ka, d.ffVx + (size_t)n0 * d.ka, (size_t)d.ka, d.ka / G64_KC};
+  const G64Seg sl{d.lamw + ((size_t)wt.g * d.wcap + wt.m0) * d.np, (size_t)d.np, d.ffVl + (size_t)n0 * d.ffW, (size_t)d.ffW, K1 / G64_KC};
+  g64_tile<false>(acc, sx, sl, g64_sm, rowoff);              // (the minus sign of the Pinv block is in Vl)
+  double* Tt = d.T + (size_t)tm * 128 * d.ffr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wr * 64 + i * 16 + (lane >> 4) + 4 * r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Tt[(size_t)row * d.ffr + n0 + wc * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+}
+
+// First-move calls: |T_p| and the smallest distance of a bound from zero per row of T (one wave per row).
+static __global__ __launch_bounds__(256) void asm_wide_tnorm_k(AsmDev d, int ntm) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= ntm * 128) return;
+  WideTile wt;
+  const bool ok = wide_tile_of(d, row >> 7, wt) && wt.m0 + (row & 127) < wt.cnt;
+  double s = 0.0, sl = 1e300;
+  if (ok) {
+    const int p = d.wlist[(size_t)wt.g * d.wcap + wt.m0 + (row & 127)];
+    for (int k = lane; k < d.ffr; k += 64) { const double t = d.T[(size_t)row * d.ffr + k]; s += t * t; }
+    for (int k = lane; k < d.nu; k += 64) sl = fmin(sl, fmin(d.ub[(size_t)p * d.nu + k], -d.lb[(size_t)p * d.nu + k]));
+  }
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); sl = fmin(sl, __shfl_xor(sl, off)); }
+  if (lane == 0) {
+    d.tnorm[row] = ok ? sqrt(s) * (1.0 + 1e-12) : 0.0;       // rows without a problem never ask for a tile
+    d.tslack[row] = ok ? sl - d.bound_tol : 1e300;           // (a NaN bound or T entry fails "<=": the tile is evaluated)
+  }
+}
+
+// max |U V' - M| over the far block: row j of the block (column W + j of the problem), all n_aug + W columns of M.
+static __global__ __launch_bounds__(256) void far_verify_k(const double* __restrict__ U, const double* __restrict__ Vx, const double* __restrict__ Vl,
+                                                           const double* __restrict__ Kunc, const double* __restrict__ H, int W, int rp, int ka, int np,
+                                                           unsigned long long* __restrict__ emax) {
+  extern __shared__ double urow[];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < rp; i += 256) urow[i] = U[(size_t)j * rp + i];
+  __syncthreads();
+  double e = 0.0;
+  for (int k = tid; k < ka + W; k += 256) {
+    double s = 0.0;
+    if (k < ka) { for (int i = 0; i < rp; ++i) s += urow[i] * Vx[(size_t)i * ka + k]; s -= Kunc[(size_t)(W + j) * ka + k]; }
+    else { for (int i = 0; i < rp; ++i) s += urow[i] * Vl[(size_t)i * W + (k - ka)]; s += H[(size_t)(W + j) * np + (k - ka)]; }
+    e = fmax(e, fabs(s));
+    if (!(s == s)) e = 1e300;
+  }
+  for (int off = 32; off > 0; off >>= 1) e = fmax(e, __shfl_xor(e, off));
+  if ((tid & 63) == 0) atomicMax(emax, (unsigned long long)__double_as_longlong(e));   // (non-negative doubles order like integers)
 }
 
 }  // namespace nnmpc

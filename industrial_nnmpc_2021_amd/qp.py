@@ -29,7 +29,7 @@ class BatchedBoxQP:
     stage and tiled along the horizon like the reference's _get_h).
     """
 
-    def __init__(self, P, tq, nu, *, Kunc="auto", method="auto", max_batch=1024, nb=0, ipm_tol=0.0,
+    def __init__(self, P, tq, nu, *, Kunc="auto", method="auto", farfield="auto", max_batch=1024, nb=0, ipm_tol=0.0,
                  max_rounds=0, max_ipm_iters=0, max_polish_rounds=0, max_refine=0, sub_steps=0, stale_max_changes=0, stale_cg_limit=0, asm_max_active=0,
                  asm_max_rounds=0, asm_f32_rounds=0, seg_max=0, asm_tail_batch=0):
         lib = _lib.load()
@@ -81,13 +81,55 @@ class BatchedBoxQP:
             else:
                 _lib.check(rc, "nnmpc_qp_set_inverse")
                 self.have_inverse = True
+        # far-field form of the full-width pass (include/nnmpc.h: nnmpc_qp_set_farfield): "auto" factors the far block
+        # for a window the first time a call's full-width pass had to do without (one-time host setup like the inverse:
+        # an fp64 SVD, ~1.5 s at the CDU size); a list of windows factors them now; None / False never
+        self._ff_src = (Hinv, Kunc) if (self.have_inverse and farfield) else None
+        self._ff_done = set()
+        if self._ff_src is not None and not isinstance(farfield, str):
+            for W in farfield:
+                self.prepare_farfield(int(W))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.nnmpc_qp_destroy(self._h)
             self._h = C.c_void_p()
+        self._ff_src = None
 
     __del__ = close
+
+    def prepare_farfield(self, W, rtol=1e-13):
+        """Factor M = [Kunc[W:] | -Hinv[W:, 0:W]] = U [Vx | Vl] (truncated SVD: singular values above rtol times the
+        largest; M has numerical rank ~Nx) and hand the factors to the library, which verifies them on the device.
+        Returns the rank, or 0 when W is not a window the full-width pass can use."""
+        if self._ff_src is None or W in self._ff_done:
+            return 0
+        self._ff_done.add(W)
+        Hinv, Kunc = self._ff_src
+        if W <= 0 or W % 128 or W >= self.n or self.n % 128:
+            return 0
+        import scipy.linalg as sla
+        M = np.hstack((Kunc[W:], -Hinv[W:, :W]))
+        U, s, Vt = sla.svd(M, full_matrices=False, lapack_driver="gesdd")
+        r = max(1, int((s > rtol * s[0]).sum()))
+        Uf = np.ascontiguousarray(U[:, :r] * s[:r])
+        Vx, Vl = np.ascontiguousarray(Vt[:r, :self.n_aug]), np.ascontiguousarray(Vt[:r, self.n_aug:])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = self._lib.nnmpc_qp_set_farfield(self._h, W, r, p(Uf), p(Vx), p(Vl))
+        if rc == _lib.EINVAL:                        # refused (rank too large for the workspace, factors too inaccurate): dense form stays
+            import warnings
+            warnings.warn("BatchedBoxQP.prepare_farfield: " + self._lib.nnmpc_last_error().decode(errors="replace"), RuntimeWarning)
+            return 0
+        _lib.check(rc, "nnmpc_qp_set_farfield")
+        return r
+
+    def _farfield_auto(self):
+        if self._ff_src is None:
+            return
+        W = C.c_int32(0)
+        _lib.check(self._lib.nnmpc_qp_farfield_missing(self._h, C.byref(W)), "nnmpc_qp_farfield_missing")
+        if W.value and W.value not in self._ff_done:
+            self.prepare_farfield(W.value)
 
     def solve_batch(self, x0, lb, ub, guess=None, first_move_only=False):
         """numpy in / numpy out.  x0 (B, n_aug), lb/ub (B, nu) or (nu,); guess: optional (B, n) uint8
@@ -113,6 +155,7 @@ class BatchedBoxQP:
         _lib.check(self._lib.nnmpc_qp_solve_batch_ex(
             self._h, B, p(x0), p(lb), p(ub), gp, p(u), p(act), p(status), p(iters), _lib.HOST,
             _lib.OUT_FIRST_MOVE if first_move_only else _lib.OUT_SEQUENCE), "nnmpc_qp_solve_batch_ex")
+        self._farfield_auto()
         bits = np.unpackbits(act.view(np.uint8), axis=1, bitorder="little")[:, :2 * self.n].astype(bool)
         return dict(u=u, active=bits, status=status, ipm_iters=iters[:, 0], factorizations=iters[:, 1])
 
@@ -130,6 +173,7 @@ class BatchedBoxQP:
         _lib.check(self._lib.nnmpc_qp_solve_batch_ex(
             self._h, B, q(x0), q(lb), q(ub), q(guess), q(u), q(active), q(status), q(iters), _lib.DEVICE,
             _lib.OUT_FIRST_MOVE if first_move_only else _lib.OUT_SEQUENCE), "nnmpc_qp_solve_batch_ex")
+        self._farfield_auto()
 
     def set_profiling(self, on=True):
         _lib.check(self._lib.nnmpc_qp_set_profiling(self._h, int(on)), "nnmpc_qp_set_profiling")
