@@ -44,13 +44,10 @@ constexpr int ASM_BIG32 = 256;            // largest set whose f32 rounds run wi
 constexpr int ASM_CNT_BIG64 = 37;         // counters[37]: length of list ASM_NLIST + 1 (fp64 rounds of sets of 177 .. 256 bounds: asm_lambda_wg64_k)
 constexpr int ASM_CNT_BIG32 = 36;         // counters[36]: length of list ASM_NLIST
 constexpr int ASM_GRACE = 10;       // rounds without a new minimum of infeasible indices before single exchanges take over
-constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last asm_wide_k (statistics)
-constexpr int ASM_CNT_WIDEG = 24;  // counters[24 + g]: problems of k-group g awaiting the full-width check (their rows of
-                                   // LAMW / XHW: region g, so that each region's GEMM stops at ITS last active bound),
-constexpr int ASM_CNT_WKMAX = 27;  // counters[27 + g]: that bound (from the group's definition; written by asm_bins_b_k),
+constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last asm_wide_k, counters[ASM_CNT_WKSUM]: the sum of their
+constexpr int ASM_CNT_WKSUM = 30;  // (last active index + 1) -- statistics, from the scans of asm_bins (no atomics)
 constexpr int ASM_TAIL_MB = 8;     // asm_tail_k keeps the tiles of sets of up to 128 bounds in LDS
 constexpr int ASM_CNT_TAIL = 35;   // counters[35]: problems handed to asm_tail_k
-constexpr int ASM_CNT_WDONE = 32;  // counters[32 + g]: problems of group g handled by the last asm_wide_k (statistics)
 constexpr int ASM_CNT_FFTILES = 38; // counters[38]: 128 x 128 tiles the far-field pass evaluated in first-move calls (statistics; cumulative over a segment)
 constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not certified by the inverse-error bound
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
@@ -61,8 +58,9 @@ __host__ __device__ constexpr int asm_list_counter(int list) {
 __host__ __device__ constexpr int asm_list_of_counter(int c) { return c >= ASM_CNT_F32 ? ASM_NBIN + c - ASM_CNT_F32 : c - 4; }   // size-class lists only
 constexpr int ASM_NKG = 3;         // rows of a round are ordered by the last active stage (groups: <= median, +1, beyond),
                                    // so that a 128-row block of the GEMM stops its k-loop at ITS last active bound
-constexpr int ASM_NSCAN = ASM_NLIST + 5 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, sum and max of
-                                                        // the last active indices
+constexpr int ASM_NSCAN = ASM_NLIST + 7 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, the problems the
+                                                        // full-width pass handled (number, sum of last active index + 1), sum and max of
+                                                        // the last active indices of the running problems
 constexpr int ASM_CNT_ROWS32 = 15; // counters[15]: rows of LAM32 / XH32 handed out ([2]: rows of LAM / XH)
 __host__ __device__ constexpr int asm_bin_cap(int b) { return 16 * (b + 4); }
 
@@ -128,10 +126,15 @@ struct AsmDev {
   int W;                           // columns evaluated in this round (multiple of 64, past the last active bound of any
                                    // running problem + a margin); W < n: a problem that settles inside the window is
                                    // handed to the full-width check (asm_wide_k) through the lists below
-  double* lamw;                    // [rows] multiplier rows of the problems awaiting the full-width check
-  const double* xhw;               // [rows] = lamw * H, all columns
-  int* wlist;                      // [ASM_NKG][wcap] those problems by k-group; their numbers are counters[ASM_CNT_WIDEG + g]
-  int wcap;                        // rows per region of lamw / xhw / wlist
+  // A problem that settles inside the window keeps its row of LAM (and of XH) until the full-width pass at the start of the next
+  // round: that pass runs over the fp64 rows 0..wrows-1 of the round just finished as they stand -- rows are ordered by the stage
+  // of the last active bound, kblk holds each 64-row block's k-range -- with rowprob saying whose row it is.  (Rounds 1-2 copied
+  // the multipliers into rows of a second array handed out by one atomic per problem: 80 000 same-address atomics in the round
+  // most sets settle in, 0.65 of that kernel's 0.95 ms, and 10 GB of workspace.)
+  int* rowprob;                    // [rows] problem awaiting the full-width check in this row of LAM, or -1
+  int wrows;                       // fp64 rows of the round whose settled problems the pass at hand checks
+  unsigned char* wmark;            // [nseg] set by asm_wide_k for the problems it handled, counted and cleared by asm_bins (statistics)
+  const double* xhw;               // [rows] = lam * H beyond the window (shapes the fused kernels' tiles do not fit)
   int tail_gi;                     // asm_tail_k: dual active-set steps (Goldfarb-Idnani) instead of Murty's single exchanges once block exchanges stop making progress (off: measured slower, see there)
   int use_wg;                      // sets of 145 .. 256 bounds go to the four-wave register kernels (qp_wg.h); 0: the single-wave / LDS-tile / slab kernels (A/B)
   int early64;                     // an f32 round that moves at most this many bounds is followed by an fp64 round (0: only a settled set is)
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // scan columns: 0 large sets, 1 + list, ASM_COL_ROW + prec * ASM_NKG + group (rows of LAM / LAM32), then the sum of
 // (last active index + 1) and the max index
 constexpr int ASM_COL_ROW = 3 + ASM_NLIST;
+constexpr int ASM_COL_WCNT = ASM_COL_ROW + 2 * ASM_NKG, ASM_COL_WK = ASM_COL_WCNT + 1;
 constexpr int ASM_WG_SETS = 256;   // largest set of the four-wave register kernels (qp_wg.h)
 __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + list otherwise
   run = p < d.nseg && d.state[p] == ASM_RUN;
@@ -305,8 +309,13 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
     if (lane == 0) wtot[c][wave] = __popcll(mk);
   }
   int km = kl, ks = run ? kl + 1 : 0;                        // ks: columns of LAM this row really has
-  for (int off = 32; off > 0; off >>= 1) { km = max(km, __shfl_xor(km, off)); ks += __shfl_xor(ks, off); }
-  if (lane == 0) { wtot[ASM_NSCAN - 1][wave] = km; wtot[ASM_NSCAN - 2][wave] = ks; }
+  // problems the full-width pass at the start of this round handled (asm_wide_k marked them): number, sum of (last active index + 1)
+  const bool wm = p < d.nseg && d.wmark[p] != 0;
+  int wk = 0;
+  if (wm) { const int m = d.mg[p]; wk = m > 0 ? d.idxg[(size_t)p * d.max_active + m - 1] + 1 : 1; }
+  const unsigned long long wmk = __ballot(wm);
+  for (int off = 32; off > 0; off >>= 1) { km = max(km, __shfl_xor(km, off)); ks += __shfl_xor(ks, off); wk += __shfl_xor(wk, off); }
+  if (lane == 0) { wtot[ASM_NSCAN - 1][wave] = km; wtot[ASM_NSCAN - 2][wave] = ks; wtot[ASM_COL_WCNT][wave] = __popcll(wmk); wtot[ASM_COL_WK][wave] = wk; }
   __syncthreads();
   if (run) {
     for (int w = 0; w < wave; ++w) { myrow += wtot[rcol][w]; myrank += wtot[col][w]; }
@@ -336,21 +345,15 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   if (blockIdx.x == gridDim.x - 1 && tid < ASM_NSCAN) {      // one workgroup publishes the totals
     if (tid == ASM_NSCAN - 1) {
       d.counters[3] = total[tid];
-      int nw = 0;                                             // asm_wide_k has consumed its lists: reset them
-      for (int g = 0; g < ASM_NKG; ++g) {
-        const int c = d.counters[ASM_CNT_WIDEG + g];
-        nw += c; d.counters[ASM_CNT_WDONE + g] = c; d.counters[ASM_CNT_WIDEG + g] = 0;
-        // k-range of the next full-width pass per group: the group's last possible active bound, this round's
-        // overall last bound for the open-ended group
-        d.counters[ASM_CNT_WKMAX + g] = g == ASM_NKG - 1 ? total[tid] : min(total[tid], asm_kgroup_bound(d, g));
-      }
-      d.counters[ASM_CNT_WIDE + 1] = nw;
     } else if (tid == ASM_NSCAN - 2) d.counters[0] = total[tid];   // sum of (last active index + 1): algorithmic k of the GEMM
+    else if (tid == ASM_COL_WCNT) d.counters[ASM_CNT_WIDE + 1] = total[tid];
+    else if (tid == ASM_COL_WK) d.counters[ASM_CNT_WKSUM] = total[tid];
     else if (tid == 0) d.counters[1] = total[0];
     else if (tid <= ASM_NLIST + 2) d.counters[asm_list_counter(tid - 1)] = total[tid];
     else if (tid == ASM_COL_ROW) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + g]; d.counters[2] = t; }
     else if (tid == ASM_COL_ROW + ASM_NKG) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + ASM_NKG + g]; d.counters[ASM_CNT_ROWS32] = t; }
   }
+  if (p < d.nseg) d.wmark[p] = 0;
   bool run;
   const int col = asm_scan_col(d, p, run);
   if (!run) return;
@@ -1293,27 +1296,14 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   }
   const bool settled = tot == 0 && !f32_phase;               // a set that settles in f32 is solved again in fp64
   const bool settle_wide = settled && W < d.n;               // settled inside the window: full-width check next
-  int wrow = 0;
-  if (settle_wide) {
-    if (lane == 0) {
-      const int kl = m > 0 ? idx[m - 1] : 0, g = asm_kgroup(d, kl);
-      wrow = g * d.wcap + atomicAdd(&d.counters[ASM_CNT_WIDEG + g], 1);   // once per problem (and re-entry), not per round
-      d.wlist[wrow] = p;
-    }
-    wrow = __shfl(wrow, 0);
-  }
-  // the LAM row goes back to zero (rows are handed out anew every round); a settled problem takes its
-  // multipliers along into its row of LAMW
-  {
-    double* lw = settle_wide ? d.lamw + (size_t)wrow * d.np : nullptr;
+  // the LAM row goes back to zero (rows are handed out anew every round) -- except the row of a problem that settled inside the
+  // window: the full-width pass at the start of the next round runs on it as it stands (asm_wide_k clears it afterwards)
+  if (settle_wide) { if (lane == 0) d.rowprob[d.row[p]] = p; }
+  else {
     for (int i = lane; i < m; i += 64) {
       const int a = idx[i];
-      if (f32_phase) d.lam32[orow + a] = 0.f;                // (never settles: lw is null)
-      else {
-        const double l = d.lam[orow + a];
-        d.lam[orow + a] = 0.0;
-        if (lw) lw[a] = l;
-      }
+      if (f32_phase) d.lam32[orow + a] = 0.f;
+      else d.lam[orow + a] = 0.0;
     }
   }
   bool sure = false;
@@ -1362,10 +1352,10 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
   extern __shared__ double wl_lam[];                         // [max_active] multipliers (rare path: x again, from Pinv)
   __shared__ int cnt[4];
   __shared__ double red[12];
-  const int g = blockIdx.y, tid = threadIdx.x;
-  if ((int)blockIdx.x >= d.counters[ASM_CNT_WIDEG + g]) return;
-  const int w = g * d.wcap + blockIdx.x;                     // row of LAMW / XHW: region g
-  const int p = d.wlist[w];
+  const int tid = threadIdx.x;
+  const int w = blockIdx.x;                                  // row of LAM / XH (and XHW) of the round the problem settled in
+  const int p = d.rowprob[w];
+  if (p < 0) return;
   const size_t o = (size_t)p * d.np, orow = (size_t)w * d.np;
   // columns inside the window the problem settled in (d.W is still that round's) were evaluated by that round's
   // GEMM: its row of XH is untouched until this round's GEMM; only the columns beyond come from the wide pass
@@ -1380,8 +1370,8 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
   double l1 = 0.0, lmin = 1e300;
   for (int i = tid; i < m; i += 256) {                       // multipliers of the settled set; the LAMW row goes back to zero
     const int a = idx[i];
-    const double l = d.lamw[orow + a];
-    d.lamw[orow + a] = 0.0;
+    const double l = d.lam[orow + a];
+    d.lam[orow + a] = 0.0;
     wl_lam[i] = l;
     l1 += fabs(l); lmin = fmin(lmin, fabs(l));
   }
@@ -1440,6 +1430,7 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
     }
   }
   if (tid == 0) {
+    d.wmark[p] = 1;
     if (tot == 0) {
       d.state[p] = sure ? ASM_CERT : ASM_DONE;
       if (!sure) atomicAdd(&d.counters[ASM_CNT_DONE], 1);    // rare: q and x P are formed only for these

@@ -663,8 +663,9 @@ struct nnmpc_qp {
   bool have_inverse;
   double* H64;      // np x np
   double* Kunc64;   // np x ka
-  double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch, *asm_lamw, *asm_xhw;
-  int *asm_wlist, *asm_wflag;
+  double *asm_xunc, *asm_x, *asm_lam, *asm_xh, *asm_scratch, *asm_xhw;
+  int *asm_rowprob, *asm_wflag;
+  unsigned char* asm_wmark;
   unsigned char* asm_st;
   int *asm_state, *asm_rounds, *asm_counters, *asm_biglist, *asm_status, *asm_binlist, *asm_idxg, *asm_mg, *asm_row, *asm_lrank, *asm_ctot;
   unsigned char *asm_prec, *asm_redo, *asm_alpha, *asm_rowk;
@@ -951,7 +952,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.H = h->H64; a.lb = lb_dev; a.ub = ub_dev; a.xunc = h->asm_xunc; a.q64 = h->q64_all;
   a.x = h->asm_x; a.lam = h->asm_lam; a.xh = h->asm_xh; a.px = h->asm_xh;
   a.st = h->asm_st; a.guess = guess_dev; a.state = h->asm_state; a.rounds = h->asm_rounds; a.counters = h->asm_counters;
-  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.lamw = h->asm_lamw; a.xhw = h->asm_xhw; a.wlist = h->asm_wlist; a.wflag = h->asm_wflag; a.wcap = h->seg_max; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
+  a.biglist = h->asm_biglist; a.binlist = h->asm_binlist; a.idxg = h->asm_idxg; a.mg = h->asm_mg; a.row = h->asm_row; a.tqmax = h->tqmax; a.lrank = h->asm_lrank; a.ctot = h->asm_ctot; a.prec = h->asm_prec; a.redo = h->asm_redo; a.rowk = h->asm_rowk; a.lam32 = h->asm_lam32; a.H32 = h->H32; a.xh32 = h->asm_xh32; a.alpha = h->asm_alpha; a.ninf_best = h->asm_ninf; a.hi = h->asm_hi; a.kblk = h->asm_kblk; a.nkblk = 2 * (h->seg_max / 64 + 2); a.kref = 0; a.use_f32 = h->opts.asm_f32_rounds >= 0; a.xhw = h->asm_xhw; a.rowprob = h->asm_rowprob; a.wrows = 0; a.wmark = h->asm_wmark; a.wflag = h->asm_wflag; a.W = h->np; a.scratch = h->asm_scratch; a.work = h->asm_work;
   a.u_out = u_dev; a.ldu = h->ldu; a.nout = h->nout; a.act_out = act_dev; a.status_out = h->asm_status; a.iters_out = it_dev; a.words = h->words;
   a.nseg = nprob;
   { static const int tgi = getenv("NNMPC_TAIL_GI") ? 1 : 0; a.tail_gi = tgi; }   // (the variable: diagnostics, A/B of the tail's exchange rule)
@@ -963,8 +964,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   const int lds_big = (a.max_active + ASM_TS) * 8;
   int cnt[ASM_NCNT] = {0};
   int rounds = 0;
-  int prev_run = 0;                                     // upper bound of the problems awaiting the full-width check
-  int kprev = 0, wide_cols = 0, kref_prev = 0, fused_c0 = -1;
+  int prev_rows = 0;                                    // fp64 rows of the last round (of LAM): the problems that settled in them await the full-width check
+  int kprev = 0, wide_cols = 0, fused_c0 = -1;
   HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
   if (tail_only) {
     // A call of at most 256 problems -- the lock-step chains of a task, a controller's single QP -- is finished on the
@@ -988,15 +989,15 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
   }
   for (; !tail_only && rounds < 2 * a.max_rounds + 2; ++rounds) {
-    if (prev_run) {
+    if (prev_rows) {
       // problems that settled inside last round's column window: all columns of x, once
       {
         EvScope es(h, 5, 0.0);
-        // (a.W is still last round's window: those columns are in that round's XH rows already); one launch per
-        // k-group region: its rows share a last active bound
+        // (a.W is still last round's window: those columns are in that round's XH rows already)
         const int c0 = (a.W < h->np && (h->np - a.W) % 128 == 0) ? a.W : 0;
         fused_c0 = ((h->np - c0) % 128 == 0 && !no_fuse) ? c0 : -1;     // the fused kernel's 128-column tiles fit: check in the GEMM's epilogue
-        const int ntm = (prev_run + 127) / 128 + (ASM_NKG - 1), ntn = (h->np - c0) / 128;   // row tiles of all k-groups in ONE launch
+        const int ntm = (prev_rows + 127) / 128, ntn = (h->np - c0) / 128;
+        a.wrows = prev_rows;
         const nnmpc_qp::Far* ff = nullptr;
         if (lazy && fused_c0 > 0 && !no_far) {
           for (const auto& f : h->far) if (f.W == c0) ff = &f;
@@ -1017,18 +1018,15 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         } else if (fused_c0 >= 0) {
           hipLaunchKernelGGL(asm_wide_gemm_k<WIDE_XUNC>, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, s, a, c0, ntm, ntn);
         } else {
-          for (int g = 0; g < ASM_NKG; ++g) {
-            const size_t r0 = (size_t)g * a.wcap * h->np;
-            gemm64(h, h->asm_xhw + r0 + c0, h->np, h->asm_lamw + r0, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_run + 127) / 128) * 128,
-                   h->np - c0, h->np, nullptr, 0, h->asm_counters + ASM_CNT_WKMAX + g, h->asm_counters + ASM_CNT_WIDEG + g);
-          }
+          // shapes the fused kernels' tiles do not fit: XHW = LAM Pinv beyond c0 by the plain GEMM, k-range per 64-row block
+          gemm64(h, h->asm_xhw + c0, h->np, h->asm_lam, h->np, h->H64 + (size_t)c0 * h->np, h->np, ((prev_rows + 127) / 128) * 128,
+                 h->np - c0, h->np, nullptr, 0, h->asm_kblk, nullptr, true);
         }
         wide_cols = h->np - c0;
       }
       EvScope es(h, 6, 0.0);
-      hipLaunchKernelGGL(asm_wide_k, dim3(prev_run, ASM_NKG), dim3(256), a.max_active * sizeof(double), s, a, fused_c0);
+      hipLaunchKernelGGL(asm_wide_k, dim3(prev_rows), dim3(256), a.max_active * sizeof(double), s, a, fused_c0);
     }
-    kref_prev = a.kref;
     a.kref = kprev;
     {
       EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
@@ -1041,11 +1039,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     const int n64 = cnt[2], n32 = cnt[ASM_CNT_ROWS32], nrun = n64 + n32;   // solved in fp64 / f32 this round
     if (h->profiling)                                   // flops of the full-width pass that opened this round
     {
-        double ksum = 0.0;                                // (bounds of the groups as asm_bins_b_k set them a round earlier)
-        for (int g = 0; g < ASM_NKG; ++g)
-          ksum += (double)cnt[ASM_CNT_WDONE + g] * (1 + (g == ASM_NKG - 1 ? kprev : std::min(kprev, asm_kgroup_bound_of(g, kref_prev, h->nu))));
-        double nw = 0.0;
-        for (int g = 0; g < ASM_NKG; ++g) nw += cnt[ASM_CNT_WDONE + g];
+        // (from the scans of this round's asm_bins: the problems asm_wide_k just handled, the sum of their last active index + 1)
+        const double nw = cnt[ASM_CNT_WIDE + 1], ksum = cnt[ASM_CNT_WKSUM];
         if (wide_far_rp) {
           // far-field form: T = z V (k = n_aug + own k-range) and x = T U' (k = rp) -- over all columns, or (first-move calls)
           // over the 128 x 128 tiles the certificate did not cover (device count)
@@ -1184,9 +1179,11 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     }
     {
       EvScope es(h, 6, 0.0);
+      // (rows of LAM whose problem settles inside the window are marked for the full-width pass that opens the next round)
+      if (n64) HIPCHK(hipMemsetAsync(h->asm_rowprob, 0xFF, (size_t)((n64 + 127) / 128) * 128 * sizeof(int), s));
       hipLaunchKernelGGL(asm_update_k, dim3((nprob + 3) / 4), dim3(256), 0, s, a);
     }
-    prev_run = a.W < h->n ? nrun : 0;
+    prev_rows = a.W < h->n ? n64 : 0;
   }
   // certification with P itself (rows the inverse-error bound could not certify): q = tq x0 and px = x P
   if (rounds >= 2 * a.max_rounds + 2) {                  // left by the round cap: the last counters are not final
@@ -1374,7 +1371,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   h->asm_pool = h->seg_max >= 4096 ? 1024 : 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka); A_(h->H32, (size_t)np * np);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
-  A_(h->asm_lamw, ASM_NKG * G * np); A_(h->asm_xhw, ASM_NKG * G * np); A_(h->asm_wlist, ASM_NKG * G); A_(h->asm_wflag, G);
+  A_(h->asm_xhw, (G + 256) * np); A_(h->asm_rowprob, G + 256); A_(h->asm_wflag, G); A_(h->asm_wmark, G);
   A_(h->asm_tnorm, G + 128 * (ASM_NKG + 1)); A_(h->asm_tslack, G + 128 * (ASM_NKG + 1));
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
   A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 2) * G);
@@ -1529,7 +1526,7 @@ int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, co
   const int n = h->n, np = h->np, ka = h->ka, n_aug = h->n_aug;
   const int rp = ((r + 127) / 128) * 128;
   if (W <= 0 || W % 128 != 0 || W >= n || np % 128 != 0) { set_error("nnmpc_qp_set_farfield: W = %d must be a multiple of 128 below n = %d (padded %d)", W, n, np); return NNMPC_EINVAL; }
-  if ((uint64_t)(h->seg_max + 128 * (ASM_NKG + 1)) * rp > (uint64_t)ASM_NKG * h->seg_max * np) { set_error("nnmpc_qp_set_farfield: rank %d too large for the workspace", r); return NNMPC_EINVAL; }
+  if (rp > np) { set_error("nnmpc_qp_set_farfield: rank %d too large for the workspace", r); return NNMPC_EINVAL; }
   const int nf = np - W;                                  // rows of the far block (padding rows: zero)
   std::vector<double> u((size_t)nf * rp, 0.0), vx((size_t)rp * ka, 0.0), vl((size_t)rp * W, 0.0), cu(nf / 128, 0.0);
   for (int j = 0; j < n - W; ++j)

@@ -10,7 +10,7 @@
 //    the window's end: M has numerical rank ~Nx (CDU: 252 of 796 columns, the 253rd singular value is 4e-15 of the first).
 //    With the one-time factorisation  M = U V'  (host, fp64 SVD, verified on the device: max |U V' - M| enters the
 //    certificate)
-//        T = [x0 | lam] V            asm_wide_t_k       rows x rp,    k = n_aug + own k-range
+//        T = [x0 | lam] V            asm_wide_t_k       rows x rp,    k = n_aug + the row block's k-range
 //        x[W:] = T U'                asm_wide_gemm_k<FAR>             k = rp = 256
 //    2.6 x fewer flops than the dense product at the CDU size -- the same numbers to rounding.
 //    First-move calls (NNMPC_OUT_FIRST_MOVE: nothing beyond the window is delivered, only checked) skip every 128-column
@@ -27,23 +27,19 @@ namespace nnmpc {
 
 enum { WIDE_XUNC = 0, WIDE_LAZY = 1, WIDE_FAR = 2 };
 
-// Row tiles of ONE launch over all k-groups: tile tm -> (group, first row in the group's region, rows of the group).
-struct WideTile { int g, m0, cnt; };
-__device__ __forceinline__ bool wide_tile_of(const AsmDev& d, int tm, WideTile& t) {
-  int t0 = 0;
-#pragma unroll
-  for (int g = 0; g < ASM_NKG; ++g) {
-    const int c = d.counters[ASM_CNT_WIDEG + g], nt = (c + 127) >> 7;
-    if (tm < t0 + nt) { t.g = g; t.m0 = (tm - t0) * 128; t.cnt = c; return true; }
-    t0 += nt;
-  }
-  return false;
+// Rows of the pass: the fp64 rows 0..wrows-1 of LAM of the round just finished (AsmDev::rowprob: the problem that settled in the
+// row, or -1); k-range of a 128-row tile: the last active bound of its two 64-row blocks (AsmDev::kblk, asm_bins_b_k).
+__device__ __forceinline__ int wide_tile_k(const AsmDev& d, int tm) {
+  const int kl = max(d.kblk[2 * tm], d.kblk[2 * tm + 1]);
+  return ((kl + G64_KC) / G64_KC) * G64_KC;
 }
 
 // ---- epilogue shared by the three forms: x, feasibility of the free variables, u out.  All loads of a row are issued
 // unconditionally and together (a branch per element would turn the epilogue into a chain of dependent round trips).
-template <bool XUNC>
-__device__ __forceinline__ void wide_epilogue(const AsmDev& d, const f64x4 (&acc)[4][4], const int* wl, int m0, int cntg, int n0) {
+// BEYOND: every column of the tile lies beyond the window the rows settled in (c0 > 0): all of them are free variables -- no
+// bound state to load -- and, nu dividing 32 or 16, a lane's four columns (16 apart) see two inputs at most.
+template <bool XUNC, bool BEYOND>
+__device__ __forceinline__ void wide_epilogue(const AsmDev& d, const f64x4 (&acc)[4][4], int m0, int n0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   int colj[4], kj[4];
@@ -53,13 +49,14 @@ __device__ __forceinline__ void wide_epilogue(const AsmDev& d, const f64x4 (&acc
     kj[j] = colj[j] % d.nu;
   }
   const bool colok = n0 + wc * 64 + 63 < d.n;                      // whole 64-column half inside the problem (wave-uniform)
+  const bool pair = BEYOND && colok && (32 % d.nu == 0);           // columns j and j + 2 share their input (wave-uniform)
   int prow[16];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + wr * 64 + i * 16 + (lane >> 4) + 4 * r;
-      prow[4 * i + r] = row < cntg ? wl[row] : -1;
+      prow[4 * i + r] = d.rowprob[row];                            // (-1 up to the end of the last tile)
     }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -72,10 +69,21 @@ __device__ __forceinline__ void wide_epilogue(const AsmDev& d, const f64x4 (&acc
       double xu[4], lbv[4], ubv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        sv[j] = st[colj[j]];
+        sv[j] = BEYOND ? 0 : st[colj[j]];
         xu[j] = XUNC ? d.xunc[(size_t)pc * d.np + colj[j]] : 0.0;
-        lbv[j] = d.lb[(size_t)pc * d.nu + kj[j]];
-        ubv[j] = d.ub[(size_t)pc * d.nu + kj[j]];
+      }
+      if (pair) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          lbv[j] = lbv[j + 2] = d.lb[(size_t)pc * d.nu + kj[j]];
+          ubv[j] = ubv[j + 2] = d.ub[(size_t)pc * d.nu + kj[j]];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lbv[j] = d.lb[(size_t)pc * d.nu + kj[j]];
+          ubv[j] = d.ub[(size_t)pc * d.nu + kj[j]];
+        }
       }
       int viol = 0;
 #pragma unroll
@@ -91,71 +99,72 @@ __device__ __forceinline__ void wide_epilogue(const AsmDev& d, const f64x4 (&acc
     }
 }
 
-// rows: the problems awaiting the check, all k-groups in one launch (row w of region g of LAMW -> problem
-// wlist[g * wcap + w]); columns: c0 + 128 tn ...; k-range of the multiplier segment: the group's last possible active bound
-// (counters[ASM_CNT_WKMAX + g]).  1-D grid of g64_grid(ntm, ntn) workgroups, ntm >= the row tiles of all groups.
+// columns: c0 + 128 tn ...; 1-D grid of g64_grid(ntm, ntn) workgroups, ntm = row tiles of AsmDev::wrows.
 template <int MODE>
 static __global__ __launch_bounds__(256, 2) void asm_wide_gemm_k(AsmDev d, int c0, int ntm, int ntn) {
   extern __shared__ __attribute__((aligned(16))) double g64_sm[];
   __shared__ long long rowoff[128];
   int tm, tn;
   if (!g64_tile_of(blockIdx.x, ntm, ntn, tm, tn)) return;
-  WideTile wt;
-  if (!wide_tile_of(d, tm, wt)) return;
-  const int n0 = c0 + tn * 128, tid = threadIdx.x;
-  const int* wl = d.wlist + (size_t)wt.g * d.wcap;
+  const int m0 = tm * 128, n0 = c0 + tn * 128, tid = threadIdx.x;
+  {                                                          // a tile without a settled problem has nothing to do
+    const int any = tid < 128 && d.rowprob[m0 + tid] >= 0;
+    if (!__syncthreads_or(any)) return;
+  }
   f64x4 acc[4][4];
   g64_zero(acc);
   if (MODE == WIDE_FAR) {
     if (d.ff_skip) {
       // first-move call: nothing in these columns is delivered.  |x_j| <= |U_j| |T_p| (Cauchy-Schwarz); ffcu[tn] bounds |U_j| for
       // every column at or beyond this tile, tnorm / tslack hold |T_p| (rounded up) and min_k min(ub_k, -lb_k) of the row's problem
-      const int row = tm * 128 + (tid & 127);
+      const int row = m0 + (tid & 127);
       const int need = tid < 128 && !(d.ffcu[tn] * d.tnorm[row] <= d.tslack[row]);   // (a NaN needs the check)
       if (!__syncthreads_or(need)) return;
       if (tid == 0) atomicAdd(&d.counters[ASM_CNT_FFTILES], 1);
     }
-    const G64Seg st{d.T + (size_t)tm * 128 * d.ffr, (size_t)d.ffr, d.ffU + (size_t)(n0 - c0) * d.ffr, (size_t)d.ffr, d.ffr / G64_KC};
+    const G64Seg st{d.T + (size_t)m0 * d.ffr, (size_t)d.ffr, d.ffU + (size_t)(n0 - c0) * d.ffr, (size_t)d.ffr, d.ffr / G64_KC};
     const G64Seg s1{d.T, 0, d.ffU, 0, 0};
     g64_tile<false>(acc, st, s1, g64_sm);
-    wide_epilogue<false>(d, acc, wl, wt.m0, wt.cnt, n0);
+    wide_epilogue<false, true>(d, acc, m0, n0);
     return;
   }
-  const int K1 = min(d.np, ((d.counters[ASM_CNT_WKMAX + wt.g] + G64_KC) / G64_KC) * G64_KC);
-  const G64Seg sl{d.lamw + ((size_t)wt.g * d.wcap + wt.m0) * d.np, (size_t)d.np, d.H + (size_t)n0 * d.np, (size_t)d.np, K1 / G64_KC};
-  if (MODE == WIDE_LAZY) {                                   // x0 rows of the tile's problems (rows beyond the count: row 0, never stored)
-    if (tid < 128) rowoff[tid] = (long long)(wt.m0 + tid < wt.cnt ? wl[wt.m0 + tid] : 0) * (long long)d.ka;
+  const int K1 = min(d.np, wide_tile_k(d, tm));
+  const G64Seg sl{d.lam + (size_t)m0 * d.np, (size_t)d.np, d.H + (size_t)n0 * d.np, (size_t)d.np, K1 / G64_KC};
+  if (MODE == WIDE_LAZY) {                                   // x0 rows of the tile's problems (rows without one: row 0, never stored)
+    if (tid < 128) rowoff[tid] = (long long)max(d.rowprob[m0 + tid], 0) * (long long)d.ka;
     __syncthreads();
     const G64Seg sx{d.x0, (size_t)d.ka, d.Kunc + (size_t)n0 * d.ka, (size_t)d.ka, d.ka / G64_KC};
-    g64_tile<true>(acc, sx, sl, g64_sm, rowoff);             // acc = x0 Kunc' - lamw Pinv'
-    wide_epilogue<false>(d, acc, wl, wt.m0, wt.cnt, n0);
+    g64_tile<true>(acc, sx, sl, g64_sm, rowoff);             // acc = x0 Kunc' - lam Pinv'
+    wide_epilogue<false, true>(d, acc, m0, n0);
   } else {
-    const G64Seg s1{d.lamw, 0, d.H, 0, 0};
-    g64_tile<false>(acc, sl, s1, g64_sm);                    // acc = lamw Pinv'
-    wide_epilogue<true>(d, acc, wl, wt.m0, wt.cnt, n0);
+    const G64Seg s1{d.lam, 0, d.H, 0, 0};
+    g64_tile<false>(acc, sl, s1, g64_sm);                    // acc = lam Pinv'
+    if (c0 > 0) wide_epilogue<true, true>(d, acc, m0, n0);
+    else wide_epilogue<true, false>(d, acc, m0, n0);
   }
 }
 
-// T = [x0 | lamw] [Vx | Vl]'  for all rows awaiting the check; row tile tm of the launch -> rows 128 tm .. of T.
+// T = [x0 | lam] [Vx | Vl]'  for the rows of the pass (rows of a round's LAM that did not settle give rows of T nobody reads).
 static __global__ __launch_bounds__(256, 2) void asm_wide_t_k(AsmDev d, int ntm, int ntn) {
   extern __shared__ __attribute__((aligned(16))) double g64_sm[];
   __shared__ long long rowoff[128];
   int tm, tn;
   if (!g64_tile_of(blockIdx.x, ntm, ntn, tm, tn)) return;
-  WideTile wt;
-  if (!wide_tile_of(d, tm, wt)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, n0 = tn * 128;
-  const int* wl = d.wlist + (size_t)wt.g * d.wcap;
-  const int K1 = min(d.ffW, ((d.counters[ASM_CNT_WKMAX + wt.g] + G64_KC) / G64_KC) * G64_KC);   // (Vl has ffW columns)
-  if (tid < 128) rowoff[tid] = (long long)(wt.m0 + tid < wt.cnt ? wl[wt.m0 + tid] : 0) * (long long)d.ka;
+  const int wr = wave >> 1, wc = wave & 1, m0 = tm * 128, n0 = tn * 128;
+  {
+    const int any = tid < 128 && d.rowprob[m0 + tid] >= 0;
+    if (!__syncthreads_or(any)) return;
+  }
+  const int K1 = min(d.ffW, wide_tile_k(d, tm));             // (Vl has ffW columns; every active bound lies below ffW)
+  if (tid < 128) rowoff[tid] = (long long)max(d.rowprob[m0 + tid], 0) * (long long)d.ka;
   __syncthreads();
   f64x4 acc[4][4];
   g64_zero(acc);
   const G64Seg sx{d.x0, (size_t)d.ka, d.ffVx + (size_t)n0 * d.ka, (size_t)d.ka, d.ka / G64_KC};
-  const G64Seg sl{d.lamw + ((size_t)wt.g * d.wcap + wt.m0) * d.np, (size_t)d.np, d.ffVl + (size_t)n0 * d.ffW, (size_t)d.ffW, K1 / G64_KC};
+  const G64Seg sl{d.lam + (size_t)m0 * d.np, (size_t)d.np, d.ffVl + (size_t)n0 * d.ffW, (size_t)d.ffW, K1 / G64_KC};
   g64_tile<false>(acc, sx, sl, g64_sm, rowoff);              // (the minus sign of the Pinv block is in Vl)
-  double* Tt = d.T + (size_t)tm * 128 * d.ffr;
+  double* Tt = d.T + (size_t)m0 * d.ffr;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -170,11 +179,10 @@ static __global__ __launch_bounds__(256, 2) void asm_wide_t_k(AsmDev d, int ntm,
 static __global__ __launch_bounds__(256) void asm_wide_tnorm_k(AsmDev d, int ntm) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= ntm * 128) return;
-  WideTile wt;
-  const bool ok = wide_tile_of(d, row >> 7, wt) && wt.m0 + (row & 127) < wt.cnt;
+  const int p = d.rowprob[row];
+  const bool ok = p >= 0;
   double s = 0.0, sl = 1e300;
   if (ok) {
-    const int p = d.wlist[(size_t)wt.g * d.wcap + wt.m0 + (row & 127)];
     for (int k = lane; k < d.ffr; k += 64) { const double t = d.T[(size_t)row * d.ffr + k]; s += t * t; }
     for (int k = lane; k < d.nu; k += 64) sl = fmin(sl, fmin(d.ub[(size_t)p * d.nu + k], -d.lb[(size_t)p * d.nu + k]));
   }
