@@ -37,21 +37,78 @@ BF16_PEAK_TFLOPS = 2500.0
 
 # ------------------------------------------------------------------------------------------------------------------
 # self-launch: N ranks as fresh child processes (nothing has touched the GPU in this process yet)
-def launch_ranks(argv, n):
+def launch_ranks(argv, n, script=None, timeout_s=None, poll_s=0.2):
+    """N ranks of `script` (default: this file) as fresh child processes, SUPERVISED: the launcher polls them and, on the
+    first non-zero exit or at a wall-clock limit, terminates (then kills) the others and returns non-zero -- RCCL has no
+    timeout, so a rank that died before or during ncclCommInitRank / a collective would leave the others waiting for ever
+    with every GPU held.  A rank is never re-started: a retry is a fresh launch.  Every rank gets RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT and NNMPC_JOB_KEY (a uuid4: key of the rendezvous file of the RCCL unique id,
+    distributed.job_key).  Rank 0's stdout is passed through; the failed rank's stderr is shown and named."""
+    import tempfile
+    import uuid
+    script = script or os.path.abspath(__file__)
+    timeout_s = timeout_s or float(os.environ.get("NNMPC_LAUNCH_TIMEOUT_S", "3300"))
     port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
-    procs = []
+    key = uuid.uuid4().hex
+    logs = tempfile.mkdtemp(prefix="nnmpc_launch_")
+    procs, files = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    sys.stdout.write(out.decode())
+                   MASTER_PORT=str(port), NNMPC_JOB_KEY=key,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        so, se = open(os.path.join(logs, f"rank{r}.out"), "wb"), open(os.path.join(logs, f"rank{r}.err"), "wb")
+        files.append((so, se))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=so, stderr=se))
+    t0, failed = time.time(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = (bad[0], f"exit code {codes[bad[0]]}")
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > timeout_s:
+            failed = ([r for r, c in enumerate(codes) if c is None][0], f"still running after {timeout_s:.0f} s")
+            break
+        time.sleep(poll_s)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.time()
+        while any(p.poll() is None for p in procs) and time.time() - t1 < 5.0:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    for so, se in files:
+        so.close(); se.close()
+
+    def tail(name, k=4000):
+        with open(os.path.join(logs, name), "rb") as f:
+            return f.read()[-k:].decode(errors="replace")
+    sys.stdout.write(tail("rank0.out", 1 << 24))
     sys.stdout.flush()
-    return rc
+    if failed:
+        r, why = failed
+        sys.stderr.write(f"bench.py launcher: rank {r} of {n} failed ({why}); the other ranks were stopped.  stderr of rank {r}:\n")
+        sys.stderr.write(tail(f"rank{r}.err") + "\n")
+        if r != 0:
+            sys.stderr.write("stderr of rank 0:\n" + tail("rank0.err") + "\n")
+        return 1
+    sys.stderr.write(tail("rank0.err"))
+    return 0
+
+
+def default_batch(workload, world):
+    """Problems per GPU per step.  cdu: BASELINE.json configs[2] "100k sampled x0, 1 MI355X"; at 8 GPUs configs[3] "1M sampled x0
+    sharded across 8 x MI355X" = 125 000 each; cstrs: configs[1] "10k sampled x0"."""
+    if workload == "cdu":
+        return 125000 if world == 8 else 100000
+    return 10000
 
 
 def csrc_sha():
@@ -64,19 +121,42 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+def kernel_key(name):
+    """'void nnmpc::gemm_nt_f32_k<128, true, true>(float*, ...)' -> 'gemm_nt_f32_k<128, true, true>': template instances stay apart
+    (the 128- and 64-wide instances of one template are different kernels with different traffic)."""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):                       # the argument list starts at the first '(' outside <...>
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and i > 0 and not n.startswith("(anonymous namespace)", i):
+            cut = i
+            break
+    n = n[:cut].replace("(anonymous namespace)::", "")
+    head = n[:n.index("<")] if "<" in n else n       # namespaces sit in front of the template arguments
+    return n[head.rfind("::") + 2:] if "::" in head else n
+
+
 def pmc_traffic(name):
-    """HBM bytes per launch of a kernel from profiles/pmc_hbm_<name>.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes,
-    scripts/pmc_hbm.py, gfx950 corrections applied) when that profile was taken on THIS build of the kernels; else {}."""
+    """HBM bytes of every kernel of one step from profiles/pmc_hbm_<name>.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes,
+    scripts/pmc_hbm.py, gfx950 corrections applied) when that profile was taken on THIS build of the kernels; else {}.
+    Returns ({kernel: {"per_launch": bytes, "per_step": bytes, "launches_per_step": n}}, note)."""
     f = os.path.join(ROOT, "profiles", f"pmc_hbm_{name}.json")
     if not os.path.exists(f):
         return {}, "no PMC profile for this workload"
     d = json.load(open(f))
     if d.get("csrc_sha") != csrc_sha():
         return {}, f"stale: {os.path.basename(f)} was taken on kernel sources {d.get('csrc_sha')}, this build is {csrc_sha()}"
+    steps = max(1, int(d.get("steps_profiled", 1)))
     out = {}
     for k, v in d["kernels"].items():
-        out[k.split("::")[-1].split("<")[0].split("(")[0].strip()] = v["hbm_bytes_per_launch"]
-    return out, f"profiles/{os.path.basename(f)} (FETCH_SIZE x2 + WRITE_SIZE, same kernel sources)"
+        tot = v["fetch_bytes_corrected"] + v["write_bytes"]
+        out[kernel_key(k)] = {"per_launch": v["hbm_bytes_per_launch"], "per_step": tot / steps, "launches_per_step": v["launches"] / steps}
+    return out, f"profiles/{os.path.basename(f)} (FETCH_SIZE x2 + WRITE_SIZE, same kernel sources, {steps} step(s) profiled)"
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -116,12 +196,29 @@ def _cpu_worker(args):
     return done, time.time() - t0, its
 
 
+def physical_cores():
+    """Physical cores of this host (distinct (package, core id) pairs of /proc/cpuinfo); None when it cannot be told."""
+    try:
+        seen, pkg = set(), "0"
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pkg = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                seen.add((pkg, line.split(":", 1)[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
     """Restated reference CPU path (oracle.qp.coneqp_l: cvxopt-style dense-G PDIP, fp64, one problem at a time)
-    timed on this host's cores.  Bounded sample.  Modes: (a) one process, all cores through
-    the BLAS threads; (b) one process, ONE BLAS thread; (c) nproc independent single-thread processes (the reference's
-    own parallel model).  (b), (c) at the CDU size only with --cpu-baseline full (a single-thread CDU solve takes
-    about a minute: outside the default run's budget)."""
+    timed on this host's cores.  Bounded sample.  Modes:
+      (a) `value`: one process, all cores through the BLAS threads, >= 4 CDU-size problems;
+      (b) `one_thread`: one process, ONE BLAS thread -- mode (i) of BASELINE.md;
+      (c) `nproc_processes`: independent single-thread processes, one problem each -- mode (ii), the reference's own
+          parallel model (lib/linearMPC.py:817-820).
+    At the CDU size a single-thread solve takes ~0.5-1 min, so (b) is read off (c): the per-process rate of the concurrent
+    single-thread solves (min(16, cores) processes; `--cpu-baseline full` also runs one alone)."""
     from oracle import qp as oqp
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
@@ -130,27 +227,27 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
         threads, threadpool_limits = os.cpu_count() or 1, None
     n = P.shape[0]
     model, blas = cpu_info()
+    min_done = 4 if workload == "cdu" else 32
     done, t0, its = 0, time.time(), []
     for b in range(x0.shape[0]):
         G, h = oqp.box_as_Gh(nu, N, lb[b], ub[b])
         info = {}
         oqp.coneqp_l(P, tq @ x0[b], G, h, info=info)
         its.append(info["iterations"]); done += 1
-        if time.time() - t0 > budget_s:
+        if time.time() - t0 > budget_s and done >= min_done:
+            break
+        if time.time() - t0 > 4 * budget_s:
             break
     dt = time.time() - t0
     res = {"value": done / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
            "sample": f"{done} problem(s) of the same seeded batch, n={n}, m={2 * n}, dense G, cvxopt-default tolerances, "
                      f"mean {np.mean(its):.1f} PDIP iterations, {dt:.1f} s, one process with {threads} BLAS threads",
-           "cpu_model": model, "blas": blas, "host_cores": os.cpu_count(),
+           "cpu_model": model, "blas": blas, "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(),
+           "blas_threads_used": int(threads),
            "paper_reference": ("CVXOPT 35 s/solve mean, 47 s worst on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"
                                if workload == "cdu" else
                                "CVXOPT 8-13 s/solve on a 2.4 GHz cluster CPU at the paper's N=450 (n=2700; the code ships N=90, n=540) (KumarRawlingsWright2021 p.7)")}
-    if (workload != "cdu" or full) and threadpool_limits is not None:
-        k = 4 if workload == "cdu" else 32
-        d1, t1, i1 = _cpu_worker((P, tq, nu, N, x0[:k], lb[:k], ub[:k], 1e9 if full else budget_s))
-        res["one_thread"] = {"value": d1 / t1, "unit": "solves/s", "cores": 1,
-                             "sample": f"{d1} problem(s), one process, 1 BLAS thread, {t1:.1f} s"}
+    if threadpool_limits is not None:
         import multiprocessing as mp
         nproc = min(os.cpu_count() or 1, 16 if workload == "cdu" else 64)
         per = 1 if workload == "cdu" else 4
@@ -163,6 +260,15 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
         res["nproc_processes"] = {"value": sum(r[0] for r in rr) / t2, "unit": "solves/s", "cores": len(jobs),
                                   "sample": f"{sum(r[0] for r in rr)} problems over {len(jobs)} independent processes "
                                             f"(1 BLAS thread each; the reference's parallel model, lib/linearMPC.py:817-820), {t2:.1f} s wall"}
+        rate = float(np.mean([r[0] / r[1] for r in rr]))
+        res["one_thread"] = {"value": rate, "unit": "solves/s", "cores": 1,
+                             "sample": f"mean per-process rate of those {len(jobs)} concurrent single-thread solves "
+                                       f"({np.mean([r[1] / max(1, r[0]) for r in rr]):.1f} s per problem)"}
+        if full or workload != "cdu":
+            k = 1 if workload == "cdu" else 32
+            d1, t1, _ = _cpu_worker((P, tq, nu, N, x0[:k], lb[:k], ub[:k], 1e9))
+            res["one_thread_alone"] = {"value": d1 / t1, "unit": "solves/s", "cores": 1,
+                                       "sample": f"{d1} problem(s), one process alone on the host, 1 BLAS thread, {t1:.1f} s"}
     return res
 
 
@@ -228,22 +334,37 @@ class QpBuffers:
             a.free()
 
 
+def _traffic_of(traffic, names):
+    """(average HBM bytes per launch, bytes per step, launches per step) of a group of kernels from the PMC profile, or Nones."""
+    hit = [traffic[k] for k in names if k in traffic]
+    if not hit:
+        return None, None, None
+    per_step = sum(h["per_step"] for h in hit)
+    launches = sum(h["launches_per_step"] for h in hit)
+    return per_step / max(launches, 1e-9), per_step, launches
+
+
 def lambda_rooflines(st, traffic):
     """The two instances of the multiplier kernel, each priced against the peak of its OWN number type."""
     f32 = st["asm_lambda32_flops"]
     f64 = st["asm_lambda_flops"] - f32
+    side_ms = st["asm_side_ms"]
     out = []
     for name, fl, ms, launches, peak, dt in (
             ("asm_lambda_reg32_k", f32, st["asm_lambda32_ms"], st["asm_lambda32_launches"], FP32_PEAK_TFLOPS, "f32"),
             ("asm_lambda_reg_k", f64, st["asm_lambda64_ms"], st["asm_lambda64_launches"], FP64_PEAK_TFLOPS, "f64")):
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        tr, _, _ = _traffic_of(traffic, [name])
         out.append({"kernel": f"{name} (|A| x |A| Cholesky + two substitutions per problem: one wave per problem, tiles in the MFMA "
                               f"accumulators, v_mfma_{dt}_16x16x4_{dt})", "dtype": dt, "bound": "mfma", "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic.get(name),
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": tr,
                     "launches": int(launches), "avg_launch_ms": ms / max(1, launches), "time_share": ms / st["total_ms"],
                     "algorithmic_flops": "m^3/3 + 2 m^2 per problem and round, m = size of its active set; the classes beyond 144 bounds "
-                                         "(side-stream kernels asm_lambda_reg32b_k / reg2_k / tile_k<1>) are in the flop count of their "
-                                         "number type but not in this kernel's time: `achieved` is an upper bound by their share (<= 3 %)"})
+                                         "(kernels asm_lambda_reg32b_k / wg* / tile_k<1> on three side streams, beside this kernel) are in "
+                                         "the flop count of their number type but not in this kernel's time: `achieved` is an UPPER bound; "
+                                         "`side_stream_ms` is the measured hipEvent time of those kernels (sum over the streams, both "
+                                         "number types) against this kernel's `kernel_ms`",
+                    "kernel_ms": ms, "side_stream_ms": side_ms})
     return out
 
 
@@ -293,17 +414,39 @@ def bench_qp(ctx, workload, B, steps, warmup, sx, method="auto", slots=0, seed0=
     if st["asm_solved"]:
         traffic, tnote = pmc_traffic(f"{workload}_b{B}")
         gach = st["asm_gemm_flops"] / (st["asm_gemm_ms"] * 1e-3) / 1e12
-        gemm = {"kernel": "gemm_nt_f64_128_k (x_unc = x0 Kunc', XH = LAM Pinv inside the column window, one full-width pass; the f32 "
-                          "rounds' XH32 = LAM32 Pinv32 on gemm_nt_f32_kdyn_k is in the same time and flop count)", "dtype": "f64",
-                "bound": "mfma", "achieved": gach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gach / FP64_PEAK_TFLOPS,
-                "traffic": traffic.get("gemm_nt_f64_128_k"), "launches": int(st["asm_gemm_launches"]),
+        gemm_group = ["gemm_nt_f64_t128_k", "asm_wide_t_k", "asm_wide_gemm_k<2>", "asm_wide_gemm_k<1>", "asm_wide_gemm_k<0>",
+                      "gemm_nt_f32_kdyn_k<128>", "gemm_nt_f32_kdyn_k<64>", "gemm_nt_f64_k"]
+        tr, tr_step, tr_launches = _traffic_of(traffic, gemm_group)
+        gemm = {"kernel": "fp64 MFMA GEMM group: gemm_nt_f64_t128_k (x_unc = x0 Kunc' for the leading columns, XH = LAM Pinv inside the column "
+                          "window) + the full-width pass asm_wide_t_k / asm_wide_gemm_k (far-field form: T = [x0 | lam] V, x = T U', check in "
+                          "the epilogue); the f32 rounds' XH32 = LAM32 Pinv32 on gemm_nt_f32_kdyn_k is in the same time and flop count",
+                "dtype": "f64", "bound": "mfma", "achieved": gach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gach / FP64_PEAK_TFLOPS,
+                "traffic": tr, "traffic_per_step": tr_step, "traffic_launches_per_step": tr_launches,
+                "launches": int(st["asm_gemm_launches"]),
                 "avg_launch_ms": st["asm_gemm_ms"] / max(1, st["asm_gemm_launches"]), "time_share": st["asm_gemm_ms"] / st["total_ms"],
-                "algorithmic_flops": "2 * (columns evaluated) * (own last active bound + 1) per running problem and round + x_unc = x0 Kunc' "
-                                     "+ one full-width pass per problem"}
+                "far_field_passes": int(st["asm_far_passes"]),
+                "algorithmic_flops": "the flops of the algorithm as implemented, unpadded: 2 * columns * n_aug (x_unc, leading columns) + per round "
+                                     "2 * window columns * (own last active bound + 1) per running problem + per problem ONE full-width pass: "
+                                     "far-field form 2 r (n_aug + own last active bound + 1) + 2 r (columns beyond the window) with r = the "
+                                     "padded rank of the far block (dense form, when no factors are set: 2 (n_aug + own bound + 1) columns)",
+                "algorithmic_bytes_per_step": float(B) * (n_aug + 2 * nu + n) * 8,
+                "traffic_note": "`traffic` = HBM bytes per launch averaged over the group's launches of one step, `traffic_per_step` their sum "
+                                "(PMC passes of scripts/pmc_hbm.sh); algorithmic_bytes_per_step = x0, bounds in + u* out"}
         cands = lambda_rooflines(st, traffic) + [gemm]
         cands.sort(key=lambda r: -r["time_share"])
         res["roofline"], res["roofline_secondary"], res["roofline_third"] = cands[0], cands[1], cands[2]
         res["roofline"]["traffic_unit"] = "HBM bytes per launch; " + tnote
+        # the whole step against the roofline: every part's algorithmic flops at the peak of its own number type / the step's time
+        f32l = st["asm_lambda32_flops"]
+        ideal_ms = 1e3 * (st["asm_gemm_flops"] / (FP64_PEAK_TFLOPS * 1e12) + f32l / (FP32_PEAK_TFLOPS * 1e12)
+                          + (st["asm_lambda_flops"] - f32l) / (FP64_PEAK_TFLOPS * 1e12))
+        res["roofline_step"] = {"bound": "mfma", "ideal_ms_per_step": ideal_ms / steps, "ms_per_step": 1e3 * dt / steps,
+                                "frac": ideal_ms / steps / (1e3 * dt / steps),
+                                "algorithmic_flops_per_step": {"gemm_f64": st["asm_gemm_flops"] / steps, "multiplier_f32": f32l / steps,
+                                                               "multiplier_f64": (st["asm_lambda_flops"] - f32l) / steps},
+                                "note": "sum over the parts of (algorithmic flops / peak of that part's number type) over the measured step time; the "
+                                        "f32 window GEMM is counted with the fp64 group (conservative: its flops are priced at the fp64 peak)",
+                                "hbm_bytes_per_step_all_kernels": (sum(v["per_step"] for v in traffic.values()) if traffic else None)}
         res["time_shares"] = {"multiplier_kernels_both_streams": st["asm_lambda_ms"] / st["total_ms"], "gemms": st["asm_gemm_ms"] / st["total_ms"],
                               "set_bookkeeping_kernels": st["asm_update_ms"] / st["total_ms"]}
         res["solver"]["checked_with_P_itself"] = int(st["asm_full_checks"])
@@ -484,17 +627,28 @@ def host_io_leg(ctx, h):
 
 def first_move_leg(ctx, h, steps):
     """The headline batch again with NNMPC_OUT_FIRST_MOVE: every problem solved and certified as before, only
-    useq[0:Nu] leaves the solver (all the offline simulation keeps, lib/linearMPC.py:856).  Not `value`."""
+    useq[0:Nu] leaves the solver (all the offline simulation keeps, lib/linearMPC.py:856).  Beyond the column window the
+    variables are only CHECKED in such a call: the far-field pass skips the column tiles |U_j| |T_p| <= min(ub, -lb)
+    certifies (qp_wide.h).  Compared with the sequence call on the same batch: active sets and status bit for bit, first
+    moves to the last bit.  Not `value`."""
     lib = ctx.lib
-    qp, buf = h["qp"], h["buf"]
+    qp, buf, nu = h["qp"], h["buf"], h["nu"]
     B = buf.B
+    qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.u, buf.act, buf.status, buf.iters)          # the sequence call
+    act_seq, st_seq = buf.act.to_host(), buf.status.to_host()
+    k = min(B, 8192)
+    u_seq = buf.u.to_host(k)[:, :nu]
     qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.first, buf.act, buf.status, buf.iters, first_move_only=True)
     lib.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         qp.solve_batch_device(B, buf.x0, buf.lb, buf.ub, buf.first, buf.act, buf.status, buf.iters, first_move_only=True)
     lib.synchronize(); dt = time.perf_counter() - t0
+    st = buf.status.to_host()
     return {"value": B * steps / dt, "unit": "solves/s", "ms_per_step": 1e3 * dt / steps,
-            "status_hist": np.bincount(buf.status.to_host(), minlength=3).tolist()}
+            "status_hist": np.bincount(st, minlength=3).tolist(),
+            "active_sets_equal_to_sequence_call": bool(np.array_equal(buf.act.to_host(), act_seq)),
+            "status_equal_to_sequence_call": bool(np.array_equal(st, st_seq)),
+            "max_abs_first_move_diff_vs_sequence_call": float(np.abs(buf.first.to_host(k) - u_seq).max()), "rows_compared": int(k)}
 
 
 def sweep_leg(ctx, h, sxs, steps):
@@ -553,6 +707,66 @@ def chains_leg(ctx, workload, nc, T, h=None):
            "note": "host wall clock around nnmpc_chain_run incl. the PCIe transfers of the inputs and the records"}
     ch.close(); qp.close()
     return out
+
+
+def cdu_offline_simulator(tasks, T, seed=1, procs_per_task=1):
+    """The reference's offline data-generation task at the CDU size on the synthetic plant: OfflineSimulator with a
+    PRBS-like setpoint signal on the last Nz = 4 outputs (one change per ~400 steps) and a disturbance signal on Nd = 5
+    channels (one per ~200 steps), `tasks` chains of T steps cut from ONE signal of tasks * T steps
+    (cdu_parameters.py:115-155, :211: Nsim = 357 600 = 149 x 2400)."""
+    from industrial_nnmpc_2021_amd import synthetic
+    from industrial_nnmpc_2021_amd import linearMPC as lm
+    from industrial_nnmpc_2021_amd.controller_evaluation import sample_prbs_like
+    pl = synthetic.plant("cdu")
+    A, Bm, Cm = pl["A"], pl["B"], pl["C"]
+    Nx, Nu = Bm.shape
+    Ny, Nz, Nd = Cm.shape[0], 4, 5
+    rng = np.random.default_rng(77)
+    H = np.concatenate((np.zeros((Nz, Ny - Nz)), np.eye(Nz)), axis=1)
+    Bd = rng.standard_normal((Nx, Nd)) / np.sqrt(Nx)
+    Cd = np.zeros((Ny, Nd))
+    # setpoints the input box can reach: a fraction of what the steady-state gain of the controlled outputs allows
+    Gz = H @ Cm @ np.linalg.solve(np.eye(Nx) - A, Bm)
+    amp = 0.2 * np.linalg.svd(Gz, compute_uv=False).min()
+    Nsim = tasks * procs_per_task * T
+    nchg = lambda mean: max(2, int(round(Nsim / mean)) - 2)
+    sp = sample_prbs_like(num_change=nchg(400), num_steps=Nsim, lb=-amp * np.ones((Nz, 1)), ub=amp * np.ones((Nz, 1)),
+                          mean_change=400, sigma_change=1, seed=seed)
+    sp = np.concatenate((np.zeros((Nsim, Ny - Nz)), sp), axis=1)
+    ds = sample_prbs_like(num_change=nchg(200), num_steps=Nsim, lb=-0.1 * np.ones((Nd, 1)), ub=0.1 * np.ones((Nd, 1)),
+                          mean_change=200, sigma_change=1, seed=seed + 1)
+    sim = lm.OfflineSimulator(A=A, B=Bm, C=Cm, H=H, Rs=1e-2 * np.eye(Nu), Qs=np.eye(Ny), Bd=Bd, Cd=Cd, usp=np.zeros((Nu, 1)),
+                              uprev=np.zeros((Nu, 1)), Q=pl["Q"], R=pl["R"], S=pl["S"], ulb=pl["ulb"], uub=pl["uub"], N=pl["N"],
+                              xprior=np.zeros((Nx, 1)), setpoints=sp, disturbances=ds, num_data_gen_task=tasks,
+                              num_process_per_task=procs_per_task)
+    return sim
+
+
+def chains_task_leg(ctx, tasks=149, T=2400):
+    """The reference's actual deliverable at its real length (cdu_parameters.py:211: 357 600 steps = 149 tasks x 2400): PRBS-like
+    setpoints and disturbances, target selector (deduplicated, batched: the other QP of every step, lib/linearMPC.py:851)
+    included, all chains in lock-step on the device, records back on the host.  At world > 1 the tasks are sharded over the
+    ranks (OfflineSimulator.generate_dataset: contiguous blocks of tasks, ONE gather of the records)."""
+    t0 = time.perf_counter()
+    sim = cdu_offline_simulator(tasks, T)
+    t_setup = time.perf_counter() - t0
+    ctx.sync()
+    t0 = time.perf_counter()
+    data = sim.generate_dataset(data_filename="unused", comm=ctx.comm, write_files=False, allow_uncertified=True)
+    ctx.sync()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
+    if ctx.rank != 0:
+        return None
+    ts = sim.target_selectors[0]
+    distinct = getattr(getattr(ts, "_batched", None), "last_distinct", None)
+    return {"value": tasks * T / dt, "unit": "chain-steps/s (target QP + regulator QP + model step each)", "chains": tasks, "steps_per_chain": T,
+            "samples": int(data["u"].shape[0]), "wall_s": dt, "setup_s_not_timed": t_setup, "n_gpus": ctx.world,
+            "distinct_target_pairs_on_rank0": distinct,
+            "status_hist": np.bincount(data["status"].ravel(), minlength=3).tolist(),
+            "max_abs_u": float(np.abs(data["u"]).max()), "fraction_of_moves_on_a_bound": float((np.abs(np.abs(data["u"]) - 1.0) < 1e-12).mean()),
+            "paper": "27.8 h for 3.6e5 samples on 149 cluster processes (KumarRawlingsWright2021 p.8)",
+            "note": "wall clock around OfflineSimulator.generate_dataset: target pairs (np.unique + nnmpc_ts_solve_batch), nnmpc_chain_run "
+                    "(state, targets, records in HBM), PCIe both ways" + (", the RCCL gather of the records" if ctx.world > 1 else "")}
 
 
 def bench_nn(ctx, B, steps, warmup):
@@ -665,6 +879,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only: no configs / sweep / chains legs")
     ap.add_argument("--pdip-batch", type=int, default=0)
     ap.add_argument("--parity-rows", type=int, default=32)
+    ap.add_argument("--chain-steps", type=int, default=0, help="--workload chains: simulation steps per chain (2400 = the reference's task length)")
     args = ap.parse_args()
     if args.no_cpu_baseline:
         args.cpu_baseline = "none"
@@ -683,16 +898,18 @@ def main():
             print(json.dumps(dict(out, **common)))
         return
     if args.workload == "chains":
-        out = chains_leg(ctx, "cdu", args.batch or 149, max(args.steps, 8))
+        # the reference's task layout: `--batch` chains (default 149 = cdu_parameters.py:211) x `--chain-steps` steps each
+        # (default: --steps, at least 8; 2400 = the reference's length), sharded over the ranks by contiguous blocks of tasks
+        out = chains_task_leg(ctx, args.batch or 149, args.chain_steps or max(args.steps, 8))
         if rank == 0:
-            line = {"metric": "lock-step closed-loop chain steps/sec (CDU size)"}
+            line = {"metric": "closed-loop offline data generation: chain steps/sec (CDU size; target QP + regulator QP + model step)"}
             line.update(common)
-            line.update(out)                                  # (chains' own "steps" = simulation steps per chain)
+            line.update(out)
+            line["scaling"] = "strong"                        # the task list is fixed, the ranks share it
             print(json.dumps(line))
         return
 
-    # cdu: BASELINE.json configs[2] "100k sampled x0, 1 MI355X"; at 8 GPUs configs[3] "1M sampled x0 over 8 GPUs" = 125 000 each
-    B = args.batch or ((125000 if world == 8 else 100000) if args.workload == "cdu" else 10000)
+    B = args.batch or default_batch(args.workload, world)
     extras = world == 1 and not args.no_extras
     res, h = bench_qp(ctx, args.workload, B, args.steps, args.warmup, args.sx, method=args.method, slots=args.slots,
                       want_buffers=(rank == 0 and world == 1))
@@ -725,12 +942,13 @@ def main():
         if extras:
             out["first_move_output"] = timed("first_move_output", first_move_leg, ctx, h, args.steps)
             if wl == "cdu":
-                out["sweep_sx"] = timed("sweep_sx", sweep_leg, ctx, h, [1.0, 2.0, 3.0, 4.0], 2)
+                out["sweep_sx"] = timed("sweep_sx", sweep_leg, ctx, h, [1.0, 2.0, 3.0, 4.0, 6.0], 2)
         host = h["host"]
         P, tq, nu, N = h["P"], h["tq"], h["nu"], h["N"]
         h["qp"].close(); h["buf"].free()
         if extras and wl == "cdu":
             out["chains"] = timed("chains", chains_leg, ctx, "cdu", 149, 12, dict(pl=h["pl"], P=P, tq=tq, nu=nu))
+            out["chains_task"] = timed("chains_task", chains_task_leg, ctx, 149, 2400)
             cfg = {}
             t_cfg = time.perf_counter()
             r2, h2 = bench_qp(ctx, "cstrs", 10000, max(args.steps, 5), 2, args.sx, want_buffers=True)
@@ -748,7 +966,7 @@ def main():
             out["configs"] = cfg
         if args.cpu_baseline != "none":
             out["cpu_baseline"] = timed("cpu_baseline", cpu_baseline, np.tril(P) + np.tril(P, -1).T, tq, nu, N, host[0][:64], host[1][:64], host[2][:64],
-                                        12.0 if wl == "cdu" else 10.0, wl, args.cpu_baseline == "full")
+                                        20.0 if wl == "cdu" else 10.0, wl, args.cpu_baseline == "full")
         out["leg_seconds"] = legs
     print(json.dumps(out))
 

@@ -113,6 +113,8 @@ typedef struct {
   double asm_lambda32_flops; /* the part of asm_lambda_flops solved in f32 rounds (price it against the f32 MFMA peak) */
   int64_t asm_lambda32_launches, asm_lambda64_launches;
   int64_t asm_far_passes;    /* full-width passes that ran in the far-field form (nnmpc_qp_set_farfield) */
+  double asm_side_ms;        /* hipEvent time of the multiplier kernels of the larger sets on the three side streams (they run
+                                beside asm_lambda_reg32_k / asm_lambda_reg_k; sum over the streams) */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);
@@ -175,8 +177,9 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc);
  * may be set.  First-move calls (NNMPC_OUT_FIRST_MOVE) additionally skip the 128-column tiles that
  * |x_j| <= |U_j| |T_p| <= min_k min(ub_k, -lb_k) certifies feasible -- nothing out there is delivered. */
 int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, const double* Vx, const double* Vl);
-/* *W = window of the last full-width pass that had to run in the dense form for want of such factors (0: none); the
- * host wrapper factors M for it and calls nnmpc_qp_set_farfield (one-time setup, like the inverse itself). */
+/* *W = a window whose full-width pass had to run in the dense form for want of such factors (0: none left; each window is
+ * handed out once per time it is met); the host wrapper factors M for it and calls nnmpc_qp_set_farfield (one-time setup,
+ * like the inverse itself). */
 int nnmpc_qp_farfield_missing(nnmpc_qp* h, int32_t* W);
 
 /* out (B x nu) = u[:, 0:nu] + us for HBM-resident sequences u (B rows of ldu doubles): the absolute first moves, i.e.
@@ -250,7 +253,7 @@ int nnmpc_chain_last_ms(nnmpc_chain* c, double* total_ms, double* solve_ms);
  * problem: primal-dual active-set iterations on the KKT system of the free inputs and the equalities (<= nu + nz
  * unknowns, Gaussian elimination with partial pivoting in LDS), fp64 throughout, KKT-certified. */
 typedef struct nnmpc_ts nnmpc_ts;
-/* Pr: nu x nu (symmetric positive definite), E: nz x nu, lb/ub: nu.  nu <= 64, nz <= 16. */
+/* Pr: nu x nu (symmetric positive definite), E: nz x nu, lb/ub: nu.  nu + nz <= 64 (the KKT system of a step sits on the 64 lanes of one wave), nz <= 16. */
 int nnmpc_ts_create(nnmpc_ts** out, int32_t nu, int32_t nz, const double* Pr, const double* E,
                     const double* lb, const double* ub);
 int nnmpc_ts_destroy(nnmpc_ts* h);

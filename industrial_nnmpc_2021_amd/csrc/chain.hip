@@ -452,7 +452,13 @@ int nnmpc_chain_run(nnmpc_chain* c, int32_t T, const double* xs, const double* u
     const int rc = nnmpc_qp_solve_batch_ex(c->qp, nc, c->qx0, c->lb, c->ub, (warm_start && c->have_guess) ? c->guess : nullptr,
                                            c->first, c->act, c->status, nullptr, NNMPC_DEVICE, NNMPC_OUT_FIRST_MOVE);
     solve_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (rc) return rc;
+    if (rc) {
+      // the chain state is half advanced (x, uprev of step t recorded, not stepped): drain the stream and drop the warm-start
+      // guess so that a later call starts from a consistent state (the caller should nnmpc_chain_reset)
+      hipStreamSynchronize(c->stream);
+      c->have_guess = false;
+      return rc;
+    }
     hipLaunchKernelGGL(chain_post_k, dim3(nc), dim3(256), lds, c->stream, nx, nu, nd, c->n, c->words, c->Mt, c->x, c->uprev,
                        us_t, d_t, c->first, c->act, c->status, uu_d + (size_t)t * nc * nu, st_d + (size_t)t * nc, c->guess);
     c->have_guess = true;

@@ -677,7 +677,7 @@ struct nnmpc_qp {
   // far-field factorisations of the full-width pass (nnmpc_qp_set_farfield), one per window
   struct Far { int W, r, rp; double *U, *Vx, *Vl, *cu; double efar; };
   std::vector<Far> far;
-  int far_missing = 0;      // window of the last full-width pass that ran in the dense form for want of factors
+  std::vector<int> far_missing;   // windows of full-width passes that ran in the dense form for want of factors (handed out once each)
   double p_inf = 0.0;       // max row sum of |P|
   double *asm_tnorm = nullptr, *asm_tslack = nullptr;
   double* asm_work;
@@ -745,14 +745,14 @@ size_t ev_get(nnmpc_qp* h) {
   return h->ev_used++;
 }
 struct EvScope {
-  nnmpc_qp* h; int kind; double flops; size_t e0;
-  EvScope(nnmpc_qp* h_, int kind_, double flops_) : h(h_), kind(kind_), flops(flops_), e0(0) {
-    if (h->profiling) { e0 = ev_get(h); hipEventRecord(h->ev_pool[e0], h->stream); }
+  nnmpc_qp* h; int kind; double flops; size_t e0; hipStream_t st;
+  EvScope(nnmpc_qp* h_, int kind_, double flops_, hipStream_t st_ = nullptr) : h(h_), kind(kind_), flops(flops_), e0(0), st(st_ ? st_ : h_->stream) {
+    if (h->profiling) { e0 = ev_get(h); hipEventRecord(h->ev_pool[e0], st); }
   }
   ~EvScope() {
     if (h->profiling) {
       size_t e1 = ev_get(h);
-      hipEventRecord(h->ev_pool[e1], h->stream);
+      hipEventRecord(h->ev_pool[e1], st);
       h->ev_recs.push_back({kind, e0, e1, flops});
     }
   }
@@ -770,6 +770,7 @@ void ev_collect(nnmpc_qp* h) {
     else if (r.kind == 6) h->stats.asm_update_ms += ms;
     else if (r.kind == 7) { h->stats.asm_lambda32_ms += ms; h->stats.asm_lambda32_launches += 1; }
     else if (r.kind == 8) { h->stats.asm_lambda64_ms += ms; h->stats.asm_lambda64_launches += 1; }
+    else if (r.kind == 9) h->stats.asm_side_ms += ms;
   }
   h->ev_recs.clear();
   h->ev_used = 0;
@@ -1001,7 +1002,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         const nnmpc_qp::Far* ff = nullptr;
         if (lazy && fused_c0 > 0 && !no_far) {
           for (const auto& f : h->far) if (f.W == c0) ff = &f;
-          if (!ff) h->far_missing = c0;                  // (the host wrapper may add the factors for this window: nnmpc_qp_farfield_missing)
+          if (!ff && h->far_missing.size() < 16 && std::find(h->far_missing.begin(), h->far_missing.end(), c0) == h->far_missing.end())
+            h->far_missing.push_back(c0);                // (the host wrapper may add the factors for this window: nnmpc_qp_farfield_missing)
         }
         a.ff_err = 0.0; a.ff_skip = 0; wide_far_rp = 0;
         if (ff) {
@@ -1010,6 +1012,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
           a.ff_err = h->p_inf * ff->efar;
           a.ff_skip = h->nout <= c0 && h->nout < h->n;
           wide_far_rp = ff->rp;
+          h->stats.asm_far_passes += 1;
           hipLaunchKernelGGL(asm_wide_t_k, dim3(g64_grid(ntm, ff->rp / 128)), dim3(256), G64_LDS, s, a, ntm, ff->rp / 128);
           if (a.ff_skip) hipLaunchKernelGGL(asm_wide_tnorm_k, dim3((ntm * 128 + 3) / 4), dim3(256), 0, s, a, ntm);
           hipLaunchKernelGGL(asm_wide_gemm_k<WIDE_FAR>, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, s, a, c0, ntm, ntn);
@@ -1047,7 +1050,6 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
           const double tiles = cnt[ASM_CNT_FFTILES] - fft_prev;
           h->stats.asm_gemm_flops += 2.0 * wide_far_rp * (ksum + nw * h->ka) +
                                      (a.ff_skip ? 2.0 * wide_far_rp * 128.0 * 128.0 * tiles : 2.0 * wide_far_rp * (double)wide_cols * nw);
-          h->stats.asm_far_passes += 1;
         } else {
           h->stats.asm_gemm_flops += 2.0 * wide_cols * (ksum + (lazy ? nw * h->ka : 0.0));   // (lazy: x_unc beyond the window is part of that pass)
         }
@@ -1133,11 +1135,12 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         HIPCHK(hipEventRecord(h->ev_fork, s));
         if (side4) {
           HIPCHK(hipStreamWaitEvent(h->stream4, h->ev_fork, 0));
-          hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream4, a, 0);
+          { EvScope e9(h, 9, 0.0, h->stream4); hipLaunchKernelGGL((asm_lambda_tile_k<1>), dim3(std::min(cnt[1], h->asm_pool)), dim3(256), lds_big, h->stream4, a, 0); }
           HIPCHK(hipEventRecord(h->ev_join4, h->stream4));
         }
         if (side2) {
           HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+          EvScope e9(h, 9, 0.0, h->stream2);
           if (nwg64) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nwg64), dim3(256), asm_wg_lds_bytes<double>(), h->stream2, a);
           if (nwg32) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nwg32), dim3(256), asm_wg_lds_bytes<float>(), h->stream2, a);
           if (cnt[ASM_CNT_BIG32] && !a.use_wg) hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(cnt[ASM_CNT_BIG32], 4096)), dim3(512), ASM_TILE32_LDS, h->stream2, a);
@@ -1145,6 +1148,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         }
         if (side3) {
           HIPCHK(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
+          EvScope e9(h, 9, 0.0, h->stream3);
           // fp64, 145 .. 176 bounds: two waves per problem (7.3 / 5.2 problems per microsecond at 160 / 176 bounds against the 6.0 / 4.5
           // of the single-wave kernel; in f32 the single-wave kernel wins, 18.1 against 14.3)
           if (nreg2_wg && a.use_wg) hipLaunchKernelGGL(asm_lambda_wg64s_k, dim3(cnt[4 + 6] + cnt[4 + 7]), dim3(128), asm_wg_lds_bytes<double>(), h->stream3, a);
@@ -1574,15 +1578,16 @@ int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, co
     f.efar = e;
     if (!(e < 1e-9)) { set_error("nnmpc_qp_set_farfield: max |U V' - M| = %.3e: the factors are not usable", e); return NNMPC_EINVAL; }
   }
-  for (auto& g : h->far) if (g.W == W) { g = f; if (h->far_missing == W) h->far_missing = 0; return NNMPC_OK; }   // (replaces; the old copies stay allocated until destroy)
+  h->far_missing.erase(std::remove(h->far_missing.begin(), h->far_missing.end(), W), h->far_missing.end());
+  for (auto& g : h->far) if (g.W == W) { g = f; return NNMPC_OK; }   // (replaces; the old copies stay allocated until destroy)
   h->far.push_back(f);
-  if (h->far_missing == W) h->far_missing = 0;
   return NNMPC_OK;
 }
 
 int nnmpc_qp_farfield_missing(nnmpc_qp* h, int32_t* W) {
   if (!h || !W) { set_error("nnmpc_qp_farfield_missing: bad arguments"); return NNMPC_EINVAL; }
-  *W = h->far_missing;
+  *W = 0;
+  if (!h->far_missing.empty()) { *W = h->far_missing.back(); h->far_missing.pop_back(); }   // handed out once: a window the caller cannot factor is not asked for again until met again
   return NNMPC_OK;
 }
 

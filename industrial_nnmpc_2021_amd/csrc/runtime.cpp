@@ -192,13 +192,22 @@ int nnmpc_comm_gather_rows(nnmpc_comm* c, const double* send, const int64_t* row
   if (c->rank == root && !recv) { set_error("nnmpc_comm_gather_rows: null receive buffer on the root"); return NNMPC_EINVAL; }
   HIPCHK(hipSetDevice(c->device));
   RCCLCHK(g_rccl.GroupStart());
-  if (rows[c->rank] > 0) RCCLCHK(g_rccl.Send(send, (size_t)rows[c->rank] * row_doubles, RCCL_FLOAT64, root, c->comm, c->stream));
-  if (c->rank == root) {
+  // An error between GroupStart and GroupEnd must not leave the group open: every later RCCL call of this thread would be
+  // queued into it instead of run.  Close the group (ignoring its result), drain the stream, then report the first error.
+  int err = RCCL_SUCCESS;
+  if (rows[c->rank] > 0) err = g_rccl.Send(send, (size_t)rows[c->rank] * row_doubles, RCCL_FLOAT64, root, c->comm, c->stream);
+  if (err == RCCL_SUCCESS && c->rank == root) {
     size_t off = 0;
-    for (int r = 0; r < c->world; ++r) {
-      if (rows[r] > 0) RCCLCHK(g_rccl.Recv(recv + off, (size_t)rows[r] * row_doubles, RCCL_FLOAT64, r, c->comm, c->stream));
+    for (int r = 0; r < c->world && err == RCCL_SUCCESS; ++r) {
+      if (rows[r] > 0) err = g_rccl.Recv(recv + off, (size_t)rows[r] * row_doubles, RCCL_FLOAT64, r, c->comm, c->stream);
       off += (size_t)rows[r] * row_doubles;
     }
+  }
+  if (err != RCCL_SUCCESS) {
+    g_rccl.GroupEnd();
+    hipStreamSynchronize(c->stream);
+    set_error("nnmpc_comm_gather_rows: ncclSend / ncclRecv: %s", g_rccl.GetErrorString(err));
+    return NNMPC_EHIP;
   }
   RCCLCHK(g_rccl.GroupEnd());
   HIPCHK(hipStreamSynchronize(c->stream));

@@ -23,28 +23,65 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def exchange_unique_id(rank, world, key, make_id, timeout_s=120.0):
-    """The 128-byte RCCL unique id of rank 0 reaches the other ranks through a file under /tmp (all ranks of a job are
-    on ONE node; ``key`` must be the same on every rank and unique to the job, e.g. MASTER_PORT + the launcher's pid)."""
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nnmpc_uid_{key}")
+def job_key():
+    """Key of the rendezvous file, the same on every rank of ONE job and different between jobs: a nonce the launcher
+    generated (``NNMPC_JOB_KEY``: bench.py's self-launch exports a uuid4; ``TORCHELASTIC_RUN_ID`` under torch.distributed.run
+    when it is not the default "none").  Without either -- ranks started by hand -- MASTER_PORT + the parent's pid has to do
+    (weak: two jobs of one shell on the default port share it; such a key's file is additionally required to be fresh)."""
+    nonce = os.environ.get("NNMPC_JOB_KEY") or os.environ.get("TORCHELASTIC_RUN_ID", "")
+    port = os.environ.get("MASTER_PORT", "0")
+    if nonce and nonce != "none":
+        return "".join(ch if ch.isalnum() else "_" for ch in nonce)[:64] + "_" + port, True
+    return f"{port}_{os.getppid()}", False
+
+
+def _uid_path(key):
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nnmpc_uid_{os.getuid()}_{key}")
+
+
+def exchange_unique_id(rank, world, key, make_id, timeout_s=120.0, strong_key=True):
+    """The 128-byte RCCL unique id of rank 0 reaches the other ranks through a file under $TMPDIR (all ranks of a job are
+    on ONE node).  ``key`` must be the same on every rank and unique to the job (``job_key()``).
+
+    Rank 0 removes whatever sits at the path (a leftover of a killed job with a recycled key), writes a private temporary
+    (O_EXCL | O_NOFOLLOW, mode 0600) and renames it into place: readers see all 128 bytes or no file, and a pre-created
+    symlink is replaced, not followed.  Readers take only a regular file of 128 bytes that this user owns with mode 0600
+    -- and, under a weak key, one written in the last few minutes: a stale id would send ncclCommInitRank into a rendezvous
+    nobody else attends, and RCCL has no timeout."""
+    path = _uid_path(key)
     if rank == 0:
         uid = make_id()
-        tmp = path + f".{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)                       # atomic: readers see all 128 bytes or no file
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
+        tmp = f"{path}.{os.getpid()}.{int.from_bytes(os.urandom(4), 'little'):08x}"
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        try:
+            os.write(fd, uid)
+        finally:
+            os.close(fd)
+        os.replace(tmp, path)
         return uid
     t0 = time.time()
     while time.time() - t0 < timeout_s:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
-        except FileNotFoundError:
+            st = os.lstat(path)
+            import stat as _stat
+            ok = (_stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0 and st.st_size == 128
+                  and (strong_key or st.st_mtime >= t0 - 300.0))
+            if ok:
+                fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                try:
+                    uid = os.read(fd, 129)
+                finally:
+                    os.close(fd)
+                if len(uid) == 128:
+                    return uid
+        except (FileNotFoundError, OSError):
             pass
         time.sleep(0.01)
-    raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s} s")
+    raise TimeoutError(f"rank {rank}: no usable RCCL unique id at {path} after {timeout_s} s")
 
 
 class Comm:
@@ -62,10 +99,11 @@ class Comm:
             if world == 1:
                 uid = make()
             else:
+                strong = True
                 if key is None:
-                    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-                uid = exchange_unique_id(self.rank, self.world, key, make)
-                self._path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nnmpc_uid_{key}")
+                    key, strong = job_key()
+                uid = exchange_unique_id(self.rank, self.world, key, make, strong_key=strong)
+                self._path = _uid_path(key)
         self._h = C.c_void_p()
         _lib.check(lib.nnmpc_comm_init(C.byref(self._h), C.c_char_p(uid), self.rank, self.world), "nnmpc_comm_init")
         if self._path and self.rank == 0:

@@ -570,3 +570,86 @@ class OfflineSimulator:
             data["data_gen_time"] = dt
             files.append(_save_training_data(data, str(task_number) + '-' + str(proc) + '-' + data_filename))
         return files
+
+    _REC_KEYS = ("x", "uprev", "xs", "us", "u")
+
+    def generate_dataset(self, *, data_filename, task_numbers=None, comm=None, rank=None, world=None, gather=None,
+                         write_files=True, allow_uncertified=False):
+        """The whole data set, sharded over the ranks of a job (one process per GPU).
+
+        The reference runs every task as its own OS process / cluster job on a contiguous slice of the scenario signal and
+        lets the per-task files meet on the file system (:786-825, controller_evaluation.py:273-295).  Here task -> rank by
+        contiguous blocks (``distributed.shard_bounds``), every rank advances ALL chains of its tasks in one lock-step batch
+        on its GPU (``simulate_chains``: state, targets and records in HBM), and ONE gather of the records -- ``comm``
+        (``distributed.Comm``: nnmpc_comm_gather_rows, RCCL over xGMI) or, in the CPU tests, a ``gather(rows, counts)``
+        callable -- brings them to rank 0, which writes the reference's per-chain files '<task>-<proc>-<data_filename>' and
+        returns what ``_post_process_data`` would return for them.  Other ranks return None.  Without ``comm`` / ``rank`` /
+        ``world`` this is the single-process case: every task in one batch.
+        """
+        from . import distributed as dd
+        tasks = list(range(self.num_data_gen_task)) if task_numbers is None else [int(t) for t in task_numbers]
+        if comm is not None:
+            rank, world = comm.rank, comm.world
+        rank, world = int(rank or 0), int(world or 1)
+        npp = self.num_process_per_task
+        cuts = [dd.shard_bounds(len(tasks), r, world) for r in range(world)]
+        mine = tasks[cuts[rank][0]:cuts[rank][1]]
+        T = self.setpoints[tasks[0]][0].shape[0] if tasks else 0
+        Nx, Nu = self.Nx, self.Nu
+        width = 2 * Nx + 3 * Nu + 2                                   # x, uprev, xs, us, u, status, data_gen_time
+        t0 = time.time()
+        if mine:
+            sp = [self.setpoints[t][c] for t in mine for c in range(npp)]
+            ds = [self.disturbances[t][c] for t in mine for c in range(npp)]
+            sel = [self.target_selectors[c] for _ in mine for c in range(npp)]
+            res = simulate_chains(self.x0, self.uprev0, self.A, self.B, self.Bd, self.regulator, self.ulb, self.uub,
+                                  sel, sp, ds, allow_uncertified=True)
+            dt = time.time() - t0
+            rec = np.concatenate([res[k] for k in self._REC_KEYS] + [res["status"][..., None].astype(float),
+                                                                    np.full(res["status"].shape + (1,), dt)], axis=2)
+            rec = np.ascontiguousarray(rec.reshape(-1, width))
+        else:
+            rec = np.empty((0, width))
+        counts = [(hi - lo) * npp * T for lo, hi in cuts]
+        if world == 1:
+            full = rec
+        elif comm is not None:
+            from . import _lib
+            send = _lib.DeviceArray.from_host(rec) if rec.size else None
+            recv = _lib.DeviceArray((sum(counts), width), np.float64) if rank == 0 else None
+            comm.gather_rows(send, counts, width, recv, root=0)        # the single collective of the job
+            full = recv.to_host() if rank == 0 else None
+            for a in (send, recv):
+                if a is not None:
+                    a.free()
+        elif gather is not None:
+            full = gather(rec, counts)
+        else:
+            raise ValueError("generate_dataset: world > 1 needs comm= (distributed.Comm) or gather=")
+        if rank != 0:
+            return None
+        full = full.reshape(len(tasks) * npp, T, width)
+        status = full[:, :, -2].astype(np.int32)
+        if not allow_uncertified and (status != 0).any():
+            c, t = np.argwhere(status != 0)[0]
+            raise RuntimeError(f"generate_dataset: {int((status != 0).sum())} regulator solve(s) not certified optimal (first: chain "
+                               f"{c}, step {t}); pass allow_uncertified=True to keep the data anyway")
+        splits = np.cumsum([Nx, Nu, Nx, Nu, Nu])
+        data = {k: [] for k in self._REC_KEYS + ("status",)}
+        times = []
+        for i, task in enumerate(tasks):
+            for proc in range(npp):
+                row = full[i * npp + proc]
+                parts = np.split(row[:, :splits[-1]], splits[:-1], axis=1)
+                one = {k: np.ascontiguousarray(v) for k, v in zip(self._REC_KEYS, parts)}
+                one["status"] = status[i * npp + proc]
+                one["data_gen_time"] = float(row[0, -1])
+                if write_files:
+                    _save_training_data(one, str(task) + '-' + str(proc) + '-' + data_filename)
+                for k in data:
+                    data[k].append(one[k])
+                times.append(one["data_gen_time"])
+        out = {k: np.concatenate(v, axis=0) for k, v in data.items()}
+        out["data_gen_time"] = float(np.mean(times)) if times else 0.0
+        return out
+

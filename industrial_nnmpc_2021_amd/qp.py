@@ -126,9 +126,11 @@ class BatchedBoxQP:
     def _farfield_auto(self):
         if self._ff_src is None:
             return
-        W = C.c_int32(0)
-        _lib.check(self._lib.nnmpc_qp_farfield_missing(self._h, C.byref(W)), "nnmpc_qp_farfield_missing")
-        if W.value and W.value not in self._ff_done:
+        for _ in range(32):                           # every window the call met without factors
+            W = C.c_int32(0)
+            _lib.check(self._lib.nnmpc_qp_farfield_missing(self._h, C.byref(W)), "nnmpc_qp_farfield_missing")
+            if not W.value:
+                break
             self.prepare_farfield(W.value)
 
     def solve_batch(self, x0, lb, ub, guess=None, first_move_only=False):

@@ -12,6 +12,8 @@ import numpy as np
 SIZES = {
     "cdu": dict(Nx=252, Nu=32, Ny=90, N=140, qw=2.0, rw=0.1, sw=0.0),
     "cstrs": dict(Nx=12, Nu=6, Ny=12, N=90, qw=1e3, rw=0.1, sw=0.1),
+    # mid-size stand-in whose padded n is a multiple of 128: the lock-step rounds with the fused full-width pass (far-field form)
+    "mid_cdu": dict(Nx=40, Nu=16, Ny=12, N=64, qw=2.0, rw=0.1, sw=0.0),
     # small stand-ins used by the CPU-oracle parity tests
     "mini_cdu": dict(Nx=24, Nu=4, Ny=8, N=20, qw=2.0, rw=0.1, sw=0.0),
     "mini_cstrs": dict(Nx=6, Nu=3, Ny=6, N=25, qw=1e3, rw=0.1, sw=0.1),

@@ -27,7 +27,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (csrc_sha: the profile is only quoted by bench.py for the kernel sources it was taken on)
 fe, tf = load(root + "/fetch", "FETCH_SIZE")
 wr, tw = load(root + "/write", "WRITE_SIZE")
-res = {"command": cmd, "csrc_sha": bench.csrc_sha(), "correction": "FETCH_SIZE x2 x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM)", "kernels": {}}
+def _steps(c):
+    """solves per kernel list in the trace: --steps + --warmup of the bench command (defaults 3 + 1)"""
+    a = c.split()
+    g = lambda k, d: int(a[a.index(k) + 1]) if k in a else d
+    return g("--steps", 3) + g("--warmup", 1)
+
+res = {"command": cmd, "csrc_sha": bench.csrc_sha(), "steps_profiled": _steps(cmd), "correction": "FETCH_SIZE x2 x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM)", "kernels": {}}
 for n, (calls, v) in sorted(fe.items(), key=lambda kv: -kv[1][1]):
     if "nnmpc" not in n: continue
     fb = v * 2 * 1024; wb = wr.get(n, [0, 0.0])[1] * 1024; ms = tf.get(n, 0.0)

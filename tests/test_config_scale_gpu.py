@@ -117,15 +117,18 @@ def test_cdu_operating_points(sx):
     u.free(); qp.close()
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 3e-2), ("bf16x3", 1e-4)])
-def test_nn_config_1m_states(mode, tol):
-    """[536, 832, 832, 832, 32] WithoutUprev (cdu_train.py:33, :77-80), 1 048 576 states through the device entry point."""
+@pytest.mark.parametrize("mode,tol,withuprev", [("f32", 1e-4, False), ("bf16", 3e-2, False), ("bf16x3", 1e-4, False),
+                                                ("f32", 1e-4, True), ("bf16", 3e-2, True)])
+def test_nn_config_1m_states(mode, tol, withuprev):
+    """[536, 832, 832, 832, 32] WithoutUprev (what the reference uses for the CDU: cdu_train.py:33, :77-80) and the 568-input
+    RegulatorLayerWithUprev BASELINE.json's config 5 names (lib/LinearMPCLayers.py:40-61), 1 048 576 states through the device
+    entry point."""
     from industrial_nnmpc_2021_amd import _lib
     from industrial_nnmpc_2021_amd.nn import StructuredNN
     from oracle import nn as onn
     rng = np.random.default_rng(0)
     nx, nu, hid, B = 252, 32, 832, 1 << 20
-    dims = [2 * nx + nu, hid, hid, hid, nu]
+    dims = [2 * nx + (2 if withuprev else 1) * nu, hid, hid, hid, nu]
     W = []
     for i in range(4):
         W.append(rng.standard_normal((dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i]))
@@ -133,18 +136,95 @@ def test_nn_config_1m_states(mode, tol):
             W.append(0.05 * rng.standard_normal(dims[i + 1]))
     xscale = rng.uniform(0.5, 2.0, nx)
     x = rng.standard_normal((B, nx)); xs = 0.3 * rng.standard_normal((B, nx)); us = rng.uniform(-0.5, 0.5, (B, nu))
+    up = us + rng.uniform(-0.3, 0.3, (B, nu)) if withuprev else None
     x[7] = xs[7]                                            # steady-state row
+    if withuprev:
+        up[7] = us[7]
     D = _lib.DeviceArray
     dx, dxs, dus, du = D.from_host(x), D.from_host(xs), D.from_host(us), D((B, nu), np.float64)
-    net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu), max_batch=262144,
+    dup = D.from_host(up) if withuprev else None
+    net = StructuredNN(W, nx, nu, nnwithuprev=withuprev, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu), max_batch=262144,
                        use_bf16={"f32": False, "bf16": True, "bf16x3": "split"}[mode])
-    net.forward_device(B, dx, None, dxs, dus, du)
+    net.forward_device(B, dx, dup, dxs, dus, du)
     u = du.to_host()
     rows = np.concatenate(([7, 0, B - 1, 262143, 262144], rng.choice(B, 4091, replace=False)))
-    ref = onn.control_input(W, x[rows], None, xs[rows], us[rows], xscale, -np.ones(nu), np.ones(nu), False)
+    ref = onn.control_input(W, x[rows], up[rows] if withuprev else None, xs[rows], us[rows], xscale, -np.ones(nu), np.ones(nu), withuprev)
     assert np.abs(u[rows] - ref).max() <= tol * max(1.0, np.abs(ref).max())
     assert np.array_equal(u[7], np.clip(us[7], -1, 1))       # both passes identical: exact
     assert np.isfinite(u).all() and (np.abs(u) <= 1.0).all()
     net.close()
-    for a in (dx, dxs, dus, du):
+    for a in (dx, dxs, dus, du, dup):
+        if a is not None:
+            a.free()
+
+
+def test_cdu_config_100k_far_field_and_first_move_calls():
+    """The 100 000-problem CDU batch again after the far-field factors of its window exist (the first call of a handle runs the
+    dense form and factors the window it met): same active sets and status, u* to rounding, the oracle on a few rows; then the
+    first-move call (NNMPC_OUT_FIRST_MOVE: column tiles beyond the window certified by |U_j| |T_p| are skipped): active sets
+    and status bit for bit, first moves to the last bit."""
+    from industrial_nnmpc_2021_amd import _lib
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    pl, P, tq, nu = _cdu()
+    B, N = 100000, pl["N"]
+    x0, lb, ub = _samples(pl, B, 1000, 2.0)
+    qp = BatchedBoxQP(P, tq, nu, max_batch=1024)
+    u1, act1, st1, _ = _solve_on_device(qp, x0, lb, ub)     # dense form; the wrapper factors the window afterwards
+    assert qp.stats()["asm_far_passes"] == 0
+    rng = np.random.default_rng(4)
+    rows = np.sort(rng.choice(B, 64, replace=False))
+    U1 = _rows(u1, rows, qp.n)
+    u1.free()
+    qp.stats(reset=True)
+    u2, act2, st2, _ = _solve_on_device(qp, x0, lb, ub)
+    assert qp.stats()["asm_far_passes"] >= 1
+    assert (st2 == 0).all() and np.array_equal(st1, st2) and np.array_equal(act1, act2)
+    U2 = _rows(u2, rows, qp.n)
+    assert np.abs(U1 - U2).max() < 1e-11
+    nact = np.unpackbits(act2.view(np.uint8), axis=1).sum(axis=1)
+    rows_oracle = np.unique(np.concatenate((np.argsort(-nact)[:3], rng.choice(B, 3, replace=False))))
+    _check(P, tq, nu, N, x0, lb, ub, u2, act2, rng.choice(B, 1000, replace=False), rows_oracle)
+    # first-move call
+    D = _lib.DeviceArray
+    dx, dl, du = D.from_host(x0), D.from_host(lb), D.from_host(ub)
+    first, act, st, it = D((B, nu), np.float64), D((B, qp.words), np.uint32), D((B,), np.int32), D((B, 2), np.int32)
+    qp.solve_batch_device(B, dx, dl, du, first, act, st, it, first_move_only=True)
+    assert np.array_equal(act.to_host(), act2) and np.array_equal(st.to_host(), st2)
+    F = first.to_host()
+    assert np.array_equal(F[rows], U2[:, :nu])
+    assert np.array_equal(F[:4096], _rows(u2, np.arange(4096), qp.n)[:, :nu])
+    for a in (dx, dl, du, first, act, st, it, u2):
         a.free()
+    qp.close()
+
+
+def test_cdu_size_chains_against_the_oracle_step_by_step():
+    """4 lock-step chains x 6 closed-loop steps at n = 4480 (simulate_offline's loop, lib/linearMPC.py:845-866): at every step
+    the recorded move equals the first move of the exact optimum (oracle.qp.solve_exact_box) of the QP the recorded state
+    defines, and the next recorded state is A x + B u + Bd d."""
+    from industrial_nnmpc_2021_amd.chain import DeviceChains
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    from tests.helpers import oracle_box_rows
+    pl, P, tq, nu = _cdu()
+    N, Nx = pl["N"], pl["A"].shape[0]
+    nc, T, Nd = 4, 6, 5
+    rng = np.random.default_rng(12)
+    Bd = rng.standard_normal((Nx, Nd)) / np.sqrt(Nx)
+    qp = BatchedBoxQP(P, tq, nu, max_batch=128, seg_max=128)
+    ch = DeviceChains(qp, nc, pl["A"], pl["B"], Bd, pl["ulb"], pl["uub"], 2.0 * rng.standard_normal(Nx), np.zeros(nu))
+    Xs = np.repeat(0.5 * rng.standard_normal((2, nc, Nx)), 3, axis=0)
+    Us = np.repeat(rng.uniform(-0.5, 0.5, (2, nc, nu)), 3, axis=0)
+    Dd = np.repeat(rng.standard_normal((3, nc, Nd)), 2, axis=0)
+    rec = ch.run(Xs, Us, Dd)
+    assert (rec["status"] == 0).all()
+    Ps = np.tril(P) + np.tril(P, -1).T
+    # every (step, chain) is one QP of the regulator: x0 = [x - xs; uprev - us], bounds shifted by us (:682-689)
+    X0 = np.concatenate((rec["x"] - Xs, rec["uprev"] - Us), axis=2).reshape(T * nc, -1)
+    LB = (pl["ulb"].T - Us).reshape(T * nc, nu); UB = (pl["uub"].T - Us).reshape(T * nc, nu)
+    sols = oracle_box_rows(Ps, tq, nu, N, X0, LB, UB, list(range(T * nc)))
+    first = np.stack([xe[:nu] for xe, _ in sols]).reshape(T, nc, nu) + Us
+    assert np.abs(rec["u"] - first).max() < 1e-8
+    assert np.abs(rec["u"]).max() > 0.999                    # the moves do hit their bounds
+    nxt = rec["x"][:-1] @ pl["A"].T + rec["u"][:-1] @ pl["B"].T + Dd[:-1] @ Bd.T
+    assert np.abs(rec["x"][1:] - nxt).max() < 1e-10 and np.abs(rec["uprev"][1:] - rec["u"][:-1]).max() == 0
+    ch.close(); qp.close()

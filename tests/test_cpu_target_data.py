@@ -116,7 +116,7 @@ def test_unique_id_reaches_every_rank_through_tmp():
     got = dict(q.get(timeout=30) for _ in range(2))
     late.join(30); first.join(30)
     assert got[0] == got[1] == bytes(range(128))
-    os.remove(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nnmpc_uid_{key}"))
+    os.remove(dd._uid_path(key))
 
 
 def test_bench_launches_its_own_ranks_before_touching_the_gpu():
