@@ -727,13 +727,14 @@ def cdu_offline_simulator(tasks, T, seed=1, procs_per_task=1):
     Cd = np.zeros((Ny, Nd))
     # setpoints the input box can reach: a fraction of what the steady-state gain of the controlled outputs allows
     Gz = H @ Cm @ np.linalg.solve(np.eye(Nx) - A, Bm)
-    amp = 0.2 * np.linalg.svd(Gz, compute_uv=False).min()
+    amp = float(os.environ.get("NNMPC_CHAIN_SP", "1.0")) * np.linalg.svd(Gz, compute_uv=False).min()
+    damp = float(os.environ.get("NNMPC_CHAIN_D", "1.0"))
     Nsim = tasks * procs_per_task * T
     nchg = lambda mean: max(2, int(round(Nsim / mean)) - 2)
     sp = sample_prbs_like(num_change=nchg(400), num_steps=Nsim, lb=-amp * np.ones((Nz, 1)), ub=amp * np.ones((Nz, 1)),
                           mean_change=400, sigma_change=1, seed=seed)
     sp = np.concatenate((np.zeros((Nsim, Ny - Nz)), sp), axis=1)
-    ds = sample_prbs_like(num_change=nchg(200), num_steps=Nsim, lb=-0.1 * np.ones((Nd, 1)), ub=0.1 * np.ones((Nd, 1)),
+    ds = sample_prbs_like(num_change=nchg(200), num_steps=Nsim, lb=-damp * np.ones((Nd, 1)), ub=damp * np.ones((Nd, 1)),
                           mean_change=200, sigma_change=1, seed=seed + 1)
     sim = lm.OfflineSimulator(A=A, B=Bm, C=Cm, H=H, Rs=1e-2 * np.eye(Nu), Qs=np.eye(Ny), Bd=Bd, Cd=Cd, usp=np.zeros((Nu, 1)),
                               uprev=np.zeros((Nu, 1)), Q=pl["Q"], R=pl["R"], S=pl["S"], ulb=pl["ulb"], uub=pl["uub"], N=pl["N"],
@@ -747,12 +748,30 @@ def chains_task_leg(ctx, tasks=149, T=2400):
     setpoints and disturbances, target selector (deduplicated, batched: the other QP of every step, lib/linearMPC.py:851)
     included, all chains in lock-step on the device, records back on the host.  At world > 1 the tasks are sharded over the
     ranks (OfflineSimulator.generate_dataset: contiguous blocks of tasks, ONE gather of the records)."""
+    from industrial_nnmpc_2021_amd import linearMPC as lm
+    from industrial_nnmpc_2021_amd.chain import DeviceChains
     t0 = time.perf_counter()
     sim = cdu_offline_simulator(tasks, T)
     t_setup = time.perf_counter() - t0
+    # where the wall time goes: the target pairs (np.unique over all steps + the batched target QP) and nnmpc_chain_run (PCIe included)
+    parts = {"target_pairs_s": 0.0, "chain_run_s": 0.0, "chain_device_s": 0.0}
+    tp0, run0 = lm._target_pairs, DeviceChains.run
+
+    def tp(*a, **k):
+        t = time.perf_counter(); r = tp0(*a, **k); parts["target_pairs_s"] += time.perf_counter() - t
+        return r
+
+    def run(self, *a, **k):
+        t = time.perf_counter(); r = run0(self, *a, **k); parts["chain_run_s"] += time.perf_counter() - t
+        parts["chain_device_s"] += self.last_ms()[0] * 1e-3
+        return r
+    lm._target_pairs, DeviceChains.run = tp, run
     ctx.sync()
     t0 = time.perf_counter()
-    data = sim.generate_dataset(data_filename="unused", comm=ctx.comm, write_files=False, allow_uncertified=True)
+    try:
+        data = sim.generate_dataset(data_filename="unused", comm=ctx.comm, write_files=False, allow_uncertified=True)
+    finally:
+        lm._target_pairs, DeviceChains.run = tp0, run0
     ctx.sync()
     dt = ctx.max_over_ranks(time.perf_counter() - t0)
     if ctx.rank != 0:
@@ -760,7 +779,8 @@ def chains_task_leg(ctx, tasks=149, T=2400):
     ts = sim.target_selectors[0]
     distinct = getattr(getattr(ts, "_batched", None), "last_distinct", None)
     return {"value": tasks * T / dt, "unit": "chain-steps/s (target QP + regulator QP + model step each)", "chains": tasks, "steps_per_chain": T,
-            "samples": int(data["u"].shape[0]), "wall_s": dt, "setup_s_not_timed": t_setup, "n_gpus": ctx.world,
+            "samples": int(data["u"].shape[0]), "wall_s": dt, "setup_s_not_timed": t_setup, "n_gpus": ctx.world, "rank0_parts": parts,
+            "device_ms_per_lockstep_step": 1e3 * parts["chain_device_s"] / max(1, T),
             "distinct_target_pairs_on_rank0": distinct,
             "status_hist": np.bincount(data["status"].ravel(), minlength=3).tolist(),
             "max_abs_u": float(np.abs(data["u"]).max()), "fraction_of_moves_on_a_bound": float((np.abs(np.abs(data["u"]) - 1.0) < 1e-12).mean()),

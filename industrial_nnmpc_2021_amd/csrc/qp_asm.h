@@ -162,11 +162,12 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
   }
   // first set: the bounds x_unc violates in the leading quarter of the horizon (where MPC saturates; a violation
   // further out is found by the full-width pass every problem goes through before it is accepted), or the guess
+  // (without a guess the host has zeroed the bound states of the segment: only the leading wi are written here)
   const int wi = d.guess ? d.n : min(d.n, max(512, ((d.n / 4 + 127) / 128) * 128));
-  for (int r = tid; r < d.n; r += 256) {
+  for (int r = tid; r < wi; r += 256) {
     int s = 0;
     if (d.guess) { s = d.guess[(size_t)p * d.n + r]; if (s > 2) s = 0; }
-    else if (r < wi) {
+    else {
       const int k = r % d.nu;
       const double x = d.xunc[o + r];
       const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
@@ -235,12 +236,51 @@ __device__ __forceinline__ int asm_count_one(const AsmDev& d, int p, int hi_p, i
   }
   return m;
 }
+// One WAVE per problem (four per workgroup): a round's sets live in the first few hundred bound states, a workgroup of 256
+// threads and two barriers per problem was launch and barrier latency (0.1 ms per round at 100 000 problems).
+__device__ __forceinline__ int asm_count_wave(const AsmDev& d, int p, int hi_p) {
+  const int lane = threadIdx.x & 63;
+  const unsigned char* st = d.st + (size_t)p * d.n;
+  const bool words = (d.n & 3) == 0;
+  const int hi = min(d.n, hi_p);
+  const int nw = words ? (hi + 3) >> 2 : hi;
+  const int per = (nw + 63) / 64;
+  const int j0 = min(nw, lane * per), j1 = min(nw, j0 + per);
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(st);
+  int c = 0;
+  if (words) {
+    for (int j = j0; j < j1; ++j) {
+      const uint32_t w = sw[j];
+      c += ((w & 0xffu) != 0) + ((w & 0xff00u) != 0) + ((w & 0xff0000u) != 0) + ((w & 0xff000000u) != 0);
+    }
+  } else {
+    for (int j = j0; j < j1; ++j) c += st[j] != 0;
+  }
+  int inc = c;
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+  const int m = __shfl(inc, 63);
+  if (m <= d.max_active && c > 0) {
+    int* idx = d.idxg + (size_t)p * d.max_active;
+    int k = inc - c;
+    if (words) {
+      for (int j = j0; j < j1; ++j) {
+        const uint32_t w = sw[j];
+        if (w & 0xffu) idx[k++] = 4 * j;
+        if (w & 0xff00u) idx[k++] = 4 * j + 1;
+        if (w & 0xff0000u) idx[k++] = 4 * j + 2;
+        if (w & 0xff000000u) idx[k++] = 4 * j + 3;
+      }
+    } else {
+      for (int j = j0; j < j1; ++j) if (st[j]) idx[k++] = j;
+    }
+  }
+  return m;
+}
 __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
-  __shared__ int wsum[4];
-  const int p = blockIdx.x, tid = threadIdx.x;
-  if (d.state[p] != ASM_RUN) return;
-  const int m = asm_count_one(d, p, d.hi[p], wsum);
-  if (tid == 0) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= d.nseg || d.state[p] != ASM_RUN) return;
+  const int m = asm_count_wave(d, p, d.hi[p]);
+  if ((threadIdx.x & 63) == 0) {
     d.mg[p] = m;
     if (m <= d.max_active && d.work) {
       const double md = (double)m;
@@ -1581,6 +1621,7 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   const double* lbp = d.lb + (size_t)p * d.nu;
   const double* ubp = d.ub + (size_t)p * d.nu;
   int best = d.ninf_best[p], grace = d.alpha[p], hi = d.hi[p], rounds = d.rounds[p];
+  if (tid == 0) d.hi[p] = d.n;                               // (from here on bounds anywhere may join: asm_certify_k scans [0, hi))
   int single = 0;                                            // the previous iteration ended with a single exchange
   int fast = 0, m = 0;                                       // dense factor valid for the current set (of size m)
   int gi = 0;                                                // dual active-set phase (see the exchange rule below)
@@ -2008,7 +2049,8 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
       for (int w = tid; w < nwd; w += 256) wb[w] = 0u;
       __syncthreads();
       // variables whose two bits fall into words [w0, w0 + nwd): stages [32 w0 / 2nu, 32 (w0 + nwd) / 2nu]
-      const int k0 = (32 * w0) / (2 * d.nu), k1 = min(d.n / d.nu, (32 * (w0 + nwd) + 2 * d.nu - 1) / (2 * d.nu));
+      // (no bound at or beyond hi[p] is active: asm_count_k's invariant -- 512 of the 4480 bound states at the CDU size)
+      const int k0 = (32 * w0) / (2 * d.nu), k1 = min((min(d.hi[p], d.n) + d.nu - 1) / d.nu, (32 * (w0 + nwd) + 2 * d.nu - 1) / (2 * d.nu));
       for (int r = k0 * d.nu + tid; r < k1 * d.nu; r += 256) {
         const int sv = st[r];
         if (sv) {

@@ -961,6 +961,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   { static const int e64 = getenv("NNMPC_EARLY64") ? atoi(getenv("NNMPC_EARLY64")) : 4; a.early64 = e64; }   // (the variable: diagnostics, A/B of the rule)
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
   // asm_update_k / asm_wide_k of the same round
+  if (!guess_dev) HIPCHK(hipMemsetAsync(h->asm_st, 0, (size_t)nprob * h->n, s));   // bound states: asm_init_k writes the leading window only
   hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
   const int lds_big = (a.max_active + ASM_TS) * 8;
   int cnt[ASM_NCNT] = {0};
@@ -1033,7 +1034,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     a.kref = kprev;
     {
       EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
-      hipLaunchKernelGGL(asm_count_k, dim3(nprob), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(asm_count_k, dim3((nprob + 3) / 4), dim3(256), 0, s, a);
       hipLaunchKernelGGL(asm_bins_a_k, dim3((nprob + 1023) / 1024), dim3(1024), 0, s, a);
       hipLaunchKernelGGL(asm_bins_b_k, dim3((nprob + 1023) / 1024), dim3(1024), 0, s, a);
     }

@@ -131,8 +131,14 @@ class TargetSelector:
         if backend not in ("hip", "host"):
             raise ValueError("backend must be 'hip' or 'host'")
         if backend == "hip" and (ylb is not None or yub is not None):
-            raise NotImplementedError("output constraints (ylb, yub) are only handled by backend='host'")
+            raise NotImplementedError("output constraints (ylb, yub) are only handled by backend='host': pass backend='host'")
         self.backend = backend
+        if backend == "hip":
+            # the reduction needs [I - A; H C] of full column rank: say so now (host fp64, no GPU involved), not at the first solve
+            sv = np.linalg.svd(np.vstack((np.eye(self.Nx) - A, H @ C)), compute_uv=False)
+            if sv.min() <= 1e-10 * sv.max():
+                raise ValueError("TargetSelector(backend='hip'): [I - A; H C] is rank deficient (integrating modes invisible to H C); "
+                                 "pass backend='host' for the full-space problem in the host solver")
         self._setup_fixed_matrices()
         self._cache = {}
         self._batched = None
@@ -450,10 +456,13 @@ def _target_pairs(target_selectors, setpoints, disturbances):
     method is asked step by step."""
     nc, T = len(setpoints), setpoints[0].shape[0]
     if all(isinstance(ts, TargetSelector) for ts in target_selectors):
-        Ysp = np.stack([np.asarray(setpoints[c], float) for c in range(nc)], axis=1)       # (T, nc, Ny)
-        Dh = np.stack([np.asarray(disturbances[c], float) for c in range(nc)], axis=1)     # (T, nc, Nd)
-        Xs, Us = target_selectors[0].solve_batch(Ysp.reshape(T * nc, -1), Dh.reshape(T * nc, -1))
-        return Xs.reshape(T, nc, -1), Us.reshape(T, nc, -1)
+        # chain-major rows: consecutive rows are consecutive steps of ONE chain, so the piecewise-constant signals give long runs
+        # of equal rows (target.unique_rows_piecewise)
+        Ysp = np.stack([np.asarray(setpoints[c], float) for c in range(nc)], axis=0)       # (nc, T, Ny)
+        Dh = np.stack([np.asarray(disturbances[c], float) for c in range(nc)], axis=0)     # (nc, T, Nd)
+        Xs, Us = target_selectors[0].solve_batch(Ysp.reshape(nc * T, -1), Dh.reshape(nc * T, -1))
+        return (np.ascontiguousarray(np.swapaxes(Xs.reshape(nc, T, -1), 0, 1)),
+                np.ascontiguousarray(np.swapaxes(Us.reshape(nc, T, -1), 0, 1)))
     first = target_selectors[0].solve(setpoints[0][0][:, None], disturbances[0][0][:, None])
     Xs, Us = np.empty((T, nc, first[0].size)), np.empty((T, nc, first[1].size))
     for c in range(nc):
