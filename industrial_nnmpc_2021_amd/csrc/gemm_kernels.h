@@ -58,15 +58,25 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kdyn_k(float* __restrict__ C,
                                                           int K, const int* __restrict__ kdyn, int kper) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   using Cf = TileCfg<NB>;
+  // 1-D grid of ntm * ntn workgroups (gridDim.y = ntm carries the row-tile count, gridDim.x = ntn * ... see the launch):
+  // workgroups go to the 8 XCDs round-robin by id, so the column tiles of ONE row panel get ids that are equal mod 8 --
+  // the panel of LAM32 comes from HBM once and from that XCD's L2 for the other column tiles (a plain (x = column tile)
+  // grid spread them over four XCDs: 3.2 GB of the step's HBM traffic for 0.8 GB of operands).
+  int tm, tn;
+  {
+    const int ntn = gridDim.x, ntm = gridDim.y, bid = blockIdx.x + ntn * blockIdx.y, full = (ntm >> 3) * 8 * ntn;
+    if (bid < full) { const int sq = bid >> 3; tm = (sq / ntn) * 8 + (bid & 7); tn = sq % ntn; }
+    else { const int rem = bid - full; tm = (ntm >> 3) * 8 + rem / ntn; tn = rem % ntn; }
+  }
   {
     // kper = 0: one bound for the launch; else kper consecutive entries per row block (64-row granularity)
-    int kl = kdyn[kper * blockIdx.y];
-    for (int i = 1; i < kper; ++i) kl = max(kl, kdyn[kper * blockIdx.y + i]);
+    int kl = kdyn[kper * tm];
+    for (int i = 1; i < kper; ++i) kl = max(kl, kdyn[kper * tm + i]);
     K = min(K, ((kl + KC) / KC) * KC);
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * NB, n0 = blockIdx.x * NB;
+  const int m0 = tm * NB, n0 = tn * NB;
   f32x16 acc[Cf::MT][Cf::MT];
   zero_acc<NB>(acc);
   PlainOp a{A + (size_t)m0 * lda, lda};

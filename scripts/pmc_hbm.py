@@ -31,7 +31,7 @@ def _steps(c):
     """solves per kernel list in the trace: --steps + --warmup of the bench command (defaults 3 + 1)"""
     a = c.split()
     g = lambda k, d: int(a[a.index(k) + 1]) if k in a else d
-    return g("--steps", 3) + g("--warmup", 1)
+    return g("--steps", 3) + g("--warmup", 1) + 1       # + the untimed setup pass of bench_qp (dense form of the full-width pass)
 
 res = {"command": cmd, "csrc_sha": bench.csrc_sha(), "steps_profiled": _steps(cmd), "correction": "FETCH_SIZE x2 x1024, WRITE_SIZE x1024 (MI355X_MICROARCH.md, HBM)", "kernels": {}}
 for n, (calls, v) in sorted(fe.items(), key=lambda kv: -kv[1][1]):

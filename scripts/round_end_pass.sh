@@ -1,14 +1,25 @@
+# One gpurun call at the end of a work block: GPU tests, smoke, kernel-trace stats, HBM and SQ counter passes, then the default
+# bench (after the HBM pass, so that its roofline.traffic quotes a profile of this very build).
+#   gpurun --timeout 1200 -- 'bash scripts/round_end_pass.sh r03a'
+# Every step's exit status is recorded in gpurun_out/<tag>_steps.txt and the script exits non-zero if any step failed
+# (a failed pytest must not leave a "complete" profile set behind).
 set -u
 T=$1
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-(timeout -k 10 500 python -m pytest tests -m gpu -q --timeout=400 -p no:cacheprovider > gpurun_out/${T}_gpu_tests.log 2>&1); tail -3 gpurun_out/${T}_gpu_tests.log
-(timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/${T}_smoke.log 2>&1); tail -1 gpurun_out/${T}_smoke.log
-(timeout -k 10 600 python bench.py > gpurun_out/${T}_cdu_b100000_bench.json 2> gpurun_out/${T}_bench.err); tail -c 300 gpurun_out/${T}_bench.err
-Q="--steps 4 --warmup 1 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io"
-(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_kt -- python3 $GRAFT_REPO_ROOT/bench.py $Q > $GRAFT_REPO_ROOT/gpurun_out/${T}_cdu_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/${T}_kt.err); 
+FAIL=0
+: > gpurun_out/${T}_steps.txt
+step() { local name=$1; shift; "$@"; local rc=$?; echo "$name rc=$rc" >> gpurun_out/${T}_steps.txt; [ $rc -ne 0 ] && FAIL=1; return 0; }
+step gpu_tests bash -c "timeout -k 10 600 python -m pytest tests -m gpu -q --timeout=500 -p no:cacheprovider > gpurun_out/${T}_gpu_tests.log 2>&1"; tail -3 gpurun_out/${T}_gpu_tests.log
+step smoke bash -c "timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/${T}_smoke.log 2>&1"; tail -1 gpurun_out/${T}_smoke.log
+Q="--steps 4 --warmup 2 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io"
+step kernel_trace bash -c "cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${T}_kt -- python3 $GRAFT_REPO_ROOT/bench.py $Q > $GRAFT_REPO_ROOT/gpurun_out/${T}_cdu_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/${T}_kt.err"
 find gpurun_out/${T}_kt -name '*kernel_stats.csv' -exec cp {} gpurun_out/${T}_cdu_b100000_kernel_stats.csv \;
-timeout -k 10 400 bash scripts/pmc_hbm.sh cdu_b100000 --steps 1 --warmup 1 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io; cp profiles/pmc_hbm_cdu_b100000.json gpurun_out/
-timeout -k 10 400 bash scripts/pmc_sq.sh ${T} --steps 1 --warmup 1 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io; cp profiles/${T}_pmc_sq.json gpurun_out/
-rm -rf gpurun_out/${T}_kt gpurun_out/pmc_hbm_cdu_b100000 gpurun_out/pmc_${T}
-ls -la gpurun_out | tail -12
+find gpurun_out/${T}_kt -name '*kernel_trace.csv' -exec cp {} gpurun_out/${T}_cdu_b100000_kernel_trace.csv \;
+python3 scripts/timeline.py gpurun_out/${T}_cdu_b100000_kernel_trace.csv > gpurun_out/${T}_cdu_b100000_timeline.txt 2>/dev/null
+step pmc_hbm bash -c "timeout -k 10 400 bash scripts/pmc_hbm.sh cdu_b100000 --steps 1 --warmup 2 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io"; cp profiles/pmc_hbm_cdu_b100000.json gpurun_out/
+step pmc_sq bash -c "timeout -k 10 400 bash scripts/pmc_sq.sh ${T} --steps 1 --warmup 2 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io"; cp profiles/${T}_pmc_sq.json gpurun_out/
+step bench bash -c "timeout -k 10 700 python bench.py > gpurun_out/${T}_cdu_b100000_bench.json 2> gpurun_out/${T}_bench.err"; tail -c 300 gpurun_out/${T}_bench.err
+rm -rf gpurun_out/${T}_kt gpurun_out/pmc_hbm_cdu_b100000 gpurun_out/pmc_${T} gpurun_out/${T}_cdu_b100000_kernel_trace.csv
+cat gpurun_out/${T}_steps.txt
+exit $FAIL
