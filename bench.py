@@ -179,9 +179,58 @@ def cpu_info():
     return model, blas
 
 
+# CPU worker processes (oracle rows of the parity leg, the single-thread processes of the CPU baseline) are forked in main()
+# BEFORE anything touches the GPU: a child forked later would inherit the KFD descriptors and Python objects whose __del__ calls
+# hipFree / nnmpc_qp_destroy -- undefined behaviour on ROCm.  Problem data reaches them through an .npz under /dev/shm.
+WORKERS = None
+_SHARED = {}
+
+
+def start_workers(n):
+    global WORKERS
+    if WORKERS is None and n > 0:
+        import multiprocessing as mp
+        WORKERS = mp.get_context("fork").Pool(n)
+    return WORKERS
+
+
+def stop_workers():
+    global WORKERS
+    if WORKERS is not None:
+        WORKERS.terminate(); WORKERS.join()
+        WORKERS = None
+
+
+def _publish(**arrays):
+    import tempfile
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    fd, path = tempfile.mkstemp(prefix="nnmpc_bench_", suffix=".npz", dir=d)
+    os.close(fd)
+    np.savez(path, **arrays)
+    return path
+
+
+def _shared(path):
+    if path not in _SHARED:
+        with np.load(path) as f:
+            _SHARED.clear()                                  # one job at a time per worker
+            _SHARED[path] = {k: f[k] for k in f.files}
+    return _SHARED[path]
+
+
+def _map(fn, jobs):
+    """jobs through the early-forked pool; without one (bench functions called from elsewhere) one after the other in this process."""
+    if WORKERS is not None:
+        return WORKERS.map(fn, jobs, chunksize=1)
+    return [fn(j) for j in jobs]
+
+
 def _cpu_worker(args):
     """One process of the reference's parallel model (lib/linearMPC.py:817-820): 1 BLAS thread, its own problems."""
-    (P, tq, nu, N, x0, lb, ub, budget_s) = args
+    (path, lo, hi, budget_s) = args
+    d = _shared(path)
+    P, tq, nu, N = d["P"], d["tq"], int(d["nu"]), int(d["N"])
+    x0, lb, ub = d["x0"][lo:hi], d["lb"][lo:hi], d["ub"][lo:hi]
     from threadpoolctl import threadpool_limits
     from oracle import qp as oqp
     done, t0, its = 0, time.time(), []
@@ -248,14 +297,14 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
                                if workload == "cdu" else
                                "CVXOPT 8-13 s/solve on a 2.4 GHz cluster CPU at the paper's N=450 (n=2700; the code ships N=90, n=540) (KumarRawlingsWright2021 p.7)")}
     if threadpool_limits is not None:
-        import multiprocessing as mp
         nproc = min(os.cpu_count() or 1, 16 if workload == "cdu" else 64)
+        if WORKERS is not None:
+            nproc = min(nproc, WORKERS._processes)
         per = 1 if workload == "cdu" else 4
-        jobs = [(P, tq, nu, N, x0[i * per:(i + 1) * per], lb[i * per:(i + 1) * per], ub[i * per:(i + 1) * per], 1e9)
-                for i in range(nproc) if (i + 1) * per <= x0.shape[0]]
+        path = _publish(P=P, tq=tq, nu=nu, N=N, x0=x0, lb=lb, ub=ub)
+        jobs = [(path, i * per, (i + 1) * per, 1e9) for i in range(nproc) if (i + 1) * per <= x0.shape[0]]
         t2 = time.time()
-        with mp.get_context("fork").Pool(len(jobs)) as pool:
-            rr = pool.map(_cpu_worker, jobs)
+        rr = _map(_cpu_worker, jobs)
         t2 = time.time() - t2
         res["nproc_processes"] = {"value": sum(r[0] for r in rr) / t2, "unit": "solves/s", "cores": len(jobs),
                                   "sample": f"{sum(r[0] for r in rr)} problems over {len(jobs)} independent processes "
@@ -266,9 +315,10 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
                                        f"({np.mean([r[1] / max(1, r[0]) for r in rr]):.1f} s per problem)"}
         if full or workload != "cdu":
             k = 1 if workload == "cdu" else 32
-            d1, t1, _ = _cpu_worker((P, tq, nu, N, x0[:k], lb[:k], ub[:k], 1e9))
+            d1, t1, _ = _cpu_worker((path, 0, k, 1e9))
             res["one_thread_alone"] = {"value": d1 / t1, "unit": "solves/s", "cores": 1,
                                        "sample": f"{d1} problem(s), one process alone on the host, 1 BLAS thread, {t1:.1f} s"}
+        os.unlink(path)
     return res
 
 
@@ -506,16 +556,12 @@ def parity_leg(h, k_oracle, k_kkt):
            "wrong_sign_multipliers": int((np.where(au, -G, 1) <= 0).sum() + (np.where(al, G, 1) <= 0).sum())}
     errs, ham, sizes = [], 0, []
     pos = {r: i for i, r in enumerate(rows_k)}
-    # the oracle solves are independent: a pool of forked workers (they inherit P and never touch the GPU), a few BLAS threads each
-    global _ORACLE_JOB
-    _ORACLE_JOB = (Ps, tq, nu, N, x0_h, lb_h, ub_h)
-    nw = max(1, min(16, len(rows_o), (os.cpu_count() or 1) // 4))
-    if nw > 1 and n >= 1024:
-        import multiprocessing as mp
-        with mp.get_context("fork").Pool(nw) as pool:
-            sols = pool.map(_oracle_row, [(int(r), max(1, (os.cpu_count() or 1) // (2 * nw))) for r in rows_o])
-    else:
-        sols = [_oracle_row((int(r), 0)) for r in rows_o]
+    # the oracle solves are independent: the worker processes forked before the first GPU call (start_workers), a few BLAS
+    # threads each; the problem data goes through /dev/shm
+    nw = WORKERS._processes if WORKERS is not None else 1
+    path = _publish(Ps=Ps, tq=tq, nu=nu, N=N, x0=x0_h[rows_o], lb=lb_h[rows_o], ub=ub_h[rows_o])
+    sols = _map(_oracle_row, [(path, i, max(1, (os.cpu_count() or 1) // (2 * nw)) if n >= 1024 else 0) for i in range(len(rows_o))])
+    os.unlink(path)
     for r, (xe, active) in zip(rows_o, sols):
         ref = np.zeros(2 * n, bool)
         ref[active] = True
@@ -527,18 +573,16 @@ def parity_leg(h, k_oracle, k_kkt):
             "largest_active_set_in_batch": int(nact.max()), "kkt_check": kkt}
 
 
-_ORACLE_JOB = None
-
-
 def _oracle_row(arg):
-    """Exact optimum and active rows of one problem of the batch (oracle.qp.solve_exact_box); runs in a forked worker."""
-    r, threads = arg
+    """Exact optimum and active rows of one problem of the batch (oracle.qp.solve_exact_box); runs in a worker process."""
+    path, i, threads = arg
     from oracle import qp as oqp
-    Ps, tq, nu, N, x0_h, lb_h, ub_h = _ORACLE_JOB
+    d = _shared(path)
+    nu, N = int(d["nu"]), int(d["N"])
 
     def run():
         info = {"nu": nu}
-        xe = oqp.solve_exact_box(Ps, tq @ x0_h[r], np.tile(lb_h[r], N), np.tile(ub_h[r], N), info=info)
+        xe = oqp.solve_exact_box(d["Ps"], d["tq"] @ d["x0"][i], np.tile(d["lb"][i], N), np.tile(d["ub"][i], N), info=info)
         return xe, info["active"]
     if threads:
         from threadpoolctl import threadpool_limits
@@ -908,6 +952,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
 
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.workload in ("cdu", "cstrs") and not (args.no_parity and args.cpu_baseline == "none"):
+        start_workers(min(16, max(1, (os.cpu_count() or 1) // 4)))     # forked BEFORE the first GPU call (see WORKERS)
     ctx = Ctx(args)
     rank, world = ctx.rank, ctx.world
     common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
@@ -989,6 +1035,7 @@ def main():
             out["cpu_baseline"] = timed("cpu_baseline", cpu_baseline, np.tril(P) + np.tril(P, -1).T, tq, nu, N, host[0][:64], host[1][:64], host[2][:64],
                                         20.0 if wl == "cdu" else 10.0, wl, args.cpu_baseline == "full")
         out["leg_seconds"] = legs
+    stop_workers()
     print(json.dumps(out))
 
 
