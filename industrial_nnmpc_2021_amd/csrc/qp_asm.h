@@ -13,11 +13,12 @@
 // Problems whose set is too large, or that do not settle, fall back to the PDIP path.
 //
 // Per round (all unfinished problems of a segment in lock-step; the host reads 24 counters once):
-//   asm_wide_k            full-width check of the problems that settled inside last round's column window
+//   asm_wide_t_k / asm_wide_gemm_k / asm_wide_k   full-width pass of the problems that settled inside last round's column
+//                         window (qp_wide.h: far-field form, check in the GEMM's epilogue)
 //   asm_count_k           ordered list of the active indices of every running problem
 //   asm_bins_a/b_k        scans: row of LAM / XH for this round (running problems packed), size-class lists
 //   asm_lambda_reg*_k     gather S = H_AA, Cholesky, lam -> row of LAM   (f32 until the set settles, then fp64)
-//   gemm_nt_f64_128_k     XH = LAM * H inside the column window          (MFMA f64)
+//   gemm_nt_f64_t128_k    XH = LAM * H inside the column window          (MFMA f64, gemm64.h)
 //   asm_update_k          x = x_unc - XH (free), x = bound (active); fp64 feasibility / multiplier-sign tests ->
 //                         next set (exchange rule with anti-cycling fallback), or settled -> full-width pass
 // and once per segment asm_init_k (first sets) and asm_certify_k (active-set bits, status, check with P itself

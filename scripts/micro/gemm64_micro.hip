@@ -7,6 +7,94 @@
 #include <cmath>
 #include "gemm_kernels.h"
 #include "gemm64.h"
+namespace nnmpc {
+// ---- round 2's tile, kept here as the reference of the A/B (it left the library in round 3)
+// Same contract, 128 x 128 tile per workgroup (2 x 2 waves of 64 x 64 = 4 x 4 MFMA tiles): half the
+// L2 -> LDS traffic per flop of the 64 x 64 kernel, which is what that one is bound by.  Needs M and the
+// grid's N multiples of 128; 74 KB of LDS (two workgroups per CU).
+static __global__ __launch_bounds__(256, 2) void gemm_nt_f64_128_k(double* __restrict__ C, size_t ldc,
+                                                                  const double* __restrict__ A, size_t lda,
+                                                                  const double* __restrict__ B, size_t ldb,
+                                                                  int K, const int* __restrict__ rowphase,
+                                                                  int want, const int* __restrict__ kdyn = nullptr,
+                                                                  const int* __restrict__ mdyn = nullptr, int kper = 0) {
+  constexpr int LD = 18, TS = 128 * LD;
+  extern __shared__ __attribute__((aligned(16))) double sm128[];   // [2][A 128 x LD | B 128 x LD]
+  if (kdyn) {
+    int kl = kdyn[kper * blockIdx.y];
+    for (int i = 1; i < kper; ++i) kl = max(kl, kdyn[kper * blockIdx.y + i]);
+    K = min(K, ((kl + 16) / 16) * 16);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  if (mdyn && m0 >= *mdyn) return;
+  if (rowphase) {
+    const int need = tid < 128 ? (rowphase[m0 + tid] == want) : 0;
+    if (!__syncthreads_or(need)) return;
+  }
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // staging: 128 rows x 16 doubles = 1024 double2 per operand -> 4 per thread
+  const int lrow0 = tid >> 3, lc = (tid & 7) * 2;           // rows lrow0 + 32 h
+  const double* Ag = A + (size_t)m0 * lda;
+  const double* Bg = B + (size_t)n0 * ldb;
+  f64x2 ra[4], rb[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    ra[h] = *reinterpret_cast<const f64x2*>(Ag + (size_t)(lrow0 + 32 * h) * lda + lc);
+    rb[h] = *reinterpret_cast<const f64x2*>(Bg + (size_t)(lrow0 + 32 * h) * ldb + lc);
+  }
+  const int li = lane & 15, kq = lane >> 4;
+  const int nk = K / 16;
+  for (int kc = 0; kc < nk; ++kc) {
+    double* sA = sm128 + (kc & 1) * 2 * TS;
+    double* sB = sA + TS;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      *reinterpret_cast<f64x2*>(sA + (lrow0 + 32 * h) * LD + lc) = ra[h];
+      *reinterpret_cast<f64x2*>(sB + (lrow0 + 32 * h) * LD + lc) = rb[h];
+    }
+    __syncthreads();
+    if (kc + 1 < nk) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        ra[h] = *reinterpret_cast<const f64x2*>(Ag + (size_t)(lrow0 + 32 * h) * lda + (kc + 1) * 16 + lc);
+        rb[h] = *reinterpret_cast<const f64x2*>(Bg + (size_t)(lrow0 + 32 * h) * ldb + (kc + 1) * 16 + lc);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = sA[(wr * 64 + t * 16 + li) * LD + 4 * s + kq];
+        b[t] = sB[(wc * 64 + t * 16 + li) * LD + 4 * s + kq];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + i * 16 + (lane >> 4) + 4 * r;
+        const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+        C[(size_t)row * ldc + col] = acc[i][j][r];
+      }
+}
+constexpr int GEMM64_128_LDS = 2 * 2 * 128 * 18 * 8;
+
+}  // namespace nnmpc
 using namespace nnmpc;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv) {
