@@ -518,7 +518,7 @@ def panel_roofline(stx, n, workload):
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic, tnote = pmc_traffic(f"{workload}_pdip")
     return {"kernel": "chol_panel_k", "dtype": "f32", "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic.get("chol_panel_k"), "traffic_unit": "HBM bytes per launch; " + tnote,
+            "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": _traffic_of(traffic, ["chol_panel_k<128>", "chol_panel_k<64>"])[0], "traffic_unit": "HBM bytes per launch; " + tnote,
             "launches": int(stx["panel_launches"]), "avg_launch_ms": ms / max(1, stx["panel_launches"]),
             "time_share": {"chol_panel": ms / stx["total_ms"], "chol_diag": stx["diag_ms"] / stx["total_ms"], "trsv": stx["trsv_ms"] / stx["total_ms"]},
             # whole-solve rate in the survey's dense-PDIP flop model: factorisations * n^3/3
@@ -834,14 +834,15 @@ def chains_task_leg(ctx, tasks=149, T=2400):
                     "(state, targets, records in HBM), PCIe both ways" + (", the RCCL gather of the records" if ctx.world > 1 else "")}
 
 
-def bench_nn(ctx, B, steps, warmup):
+def bench_nn(ctx, B, steps, warmup, with_uprev=False, modes=("f32", "bf16", "bf16x3")):
     """Config 5: structured-NN controller forward, CDU architecture [536, 832, 832, 832, 32]
-    (RegulatorLayerWithoutUprev, cdu_train.py:33, :77-80), B states per GPU per step, f32 and bf16."""
+    (RegulatorLayerWithoutUprev, what the reference uses for the CDU: cdu_train.py:33, :77-80; with_uprev: the 568-input
+    RegulatorLayerWithUprev BASELINE.json names, lib/LinearMPCLayers.py:40-61), B states per GPU per step, f32 and bf16."""
     from industrial_nnmpc_2021_amd.nn import StructuredNN
     from oracle import nn as onn
     lib = ctx.lib
     nx, nu, hid = 252, 32, 832
-    dims = [2 * nx + nu, hid, hid, hid, nu]
+    dims = [2 * nx + (2 if with_uprev else 1) * nu, hid, hid, hid, nu]
     rng = np.random.default_rng(0)
     W = []
     for i in range(4):
@@ -851,27 +852,31 @@ def bench_nn(ctx, B, steps, warmup):
     xscale = rng.uniform(0.5, 2.0, nx)
     g = np.random.default_rng(1000 + ctx.rank)
     x_h = g.standard_normal((B, nx)); xs_h = 0.3 * g.standard_normal((B, nx)); us_h = g.uniform(-0.5, 0.5, (B, nu))
+    up_h = us_h + g.uniform(-0.3, 0.3, (B, nu)) if with_uprev else None
     x_h[0] = xs_h[0]                                   # steady-state row: the structure gives u = clip(us) exactly
+    if with_uprev:
+        up_h[0] = us_h[0]
     D = lib.DeviceArray
     x, xs, us, u = D.from_host(x_h), D.from_host(xs_h), D.from_host(us_h), D((B, nu), np.float64)
+    up = D.from_host(up_h) if with_uprev else None
     flops_per_state = 2 * 2 * sum(dims[i] * dims[i + 1] for i in range(4))   # both passes
     hidden_flops_per_state = 2 * 2 * sum(dims[i] * dims[i + 1] for i in range(3))   # the three hidden-layer GEMMs
     res = {}
     k = min(B, 4096)
     rows = np.concatenate(([0], np.sort(np.random.default_rng(9).choice(B, k - 1, replace=False)))) if B > k else np.arange(B)
-    ref = onn.control_input(W, x_h[rows], None, xs_h[rows], us_h[rows], xscale, -np.ones(nu), np.ones(nu), False)
-    for mode in ("f32", "bf16", "bf16x3"):
-        net = StructuredNN(W, nx, nu, nnwithuprev=False, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu),
+    ref = onn.control_input(W, x_h[rows], up_h[rows] if with_uprev else None, xs_h[rows], us_h[rows], xscale, -np.ones(nu), np.ones(nu), with_uprev)
+    for mode in modes:
+        net = StructuredNN(W, nx, nu, nnwithuprev=with_uprev, xscale=xscale, ulb=-np.ones(nu), uub=np.ones(nu),
                            max_batch=262144, use_bf16={"f32": False, "bf16": True, "bf16x3": "split"}[mode])
         # 6 extra untimed forwards before the W warmup steps: on every box tried, ONE forward of the first ~100 ms of
         # sustained MFMA load starts ~40 ms late (device time of that call unchanged: the stream just starts later),
         # then none for the rest of the run; with K of a few steps that one stall would be a third of the timed region
         for _ in range(6 + warmup):
-            net.forward_device(B, x, None, xs, us, u)
+            net.forward_device(B, x, up, xs, us, u)
         ctx.sync()
         t0 = time.perf_counter(); gm = dm = hm = 0.0; hl = 0
         for _ in range(steps):
-            net.forward_device(B, x, None, xs, us, u)
+            net.forward_device(B, x, up, xs, us, u)
             gm += net.last_ms()[0]; dm += net.last_ms()[1]
             hm += net.last_hidden_ms()[0]; hl += net.last_hidden_ms()[1]
         ctx.sync()
@@ -885,8 +890,12 @@ def bench_nn(ctx, B, steps, warmup):
                          hidden_TFLOPs=hidden_flops_per_state * B * steps / (hm * 1e-3) / 1e12,
                          hidden_launches=hl, hidden_avg_launch_ms=hm / max(1, hl))
         net.close()
-    for a in (x, xs, us, u):
-        a.free()
+    for a in (x, xs, us, u, up):
+        if a is not None:
+            a.free()
+    if with_uprev:                                     # the variant entry of the main line: rates and errors only
+        return {"dims": dims, **{m: {k: res[m][k] for k in ("states_per_s", "ms_per_step", "max_rel_err_vs_fp64_oracle", "steady_state_row_exact",
+                                                              "hidden_TFLOPs", "rows_checked")} for m in modes}}
     f, h, s3 = res["f32"], res["bf16"], res["bf16x3"]
     traffic, tnote = pmc_traffic(f"nn_b{B}")
     rows2 = 2 * min(B, 262144)
@@ -897,7 +906,7 @@ def bench_nn(ctx, B, steps, warmup):
                       "flops_per_state": flops_per_state},
            "roofline": {"kernel": "gemm_nt_f32_k (128 x 128 tiles, v_mfma_f32_32x32x2_f32, bias + ReLU fused)", "dtype": "f32", "bound": "mfma",
                         "achieved": f["hidden_TFLOPs"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f["hidden_TFLOPs"] / FP32_PEAK_TFLOPS,
-                        "traffic": traffic.get("gemm_nt_f32_k"), "traffic_unit": "HBM bytes per launch; " + tnote,
+                        "traffic": _traffic_of(traffic, ["gemm_nt_f32_k<128, true, true>"])[0], "traffic_unit": "HBM bytes per launch of the 128-wide instance (hidden layers); " + tnote,
                         "launches": f["hidden_launches"], "avg_launch_ms": f["hidden_avg_launch_ms"],
                         "algorithmic_bytes_per_launch": rows2 * (896 + 896) * 4,
                         "algorithmic_flops": "2 passes x 2 x sum(d_in d_out) per state, unpadded (SURVEY 8d)"},
@@ -907,7 +916,7 @@ def bench_nn(ctx, B, steps, warmup):
            "bf16": dict(h, tolerance=3e-2,
                         roofline={"kernel": "gemm_nt_bf16_wide_k (256 x 208 tiles, v_mfma_f32_16x16x32_bf16, persistent workgroups)", "dtype": "bf16",
                                   "bound": "mfma", "achieved": h["hidden_TFLOPs"], "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": h["hidden_TFLOPs"] / BF16_PEAK_TFLOPS, "traffic": traffic.get("gemm_nt_bf16_wide_k"),
+                                  "frac": h["hidden_TFLOPs"] / BF16_PEAK_TFLOPS, "traffic": _traffic_of(traffic, ["gemm_nt_bf16_wide_k<true, true, false>"])[0],
                                   "traffic_unit": "HBM bytes per launch; " + tnote,
                                   "launches": h["hidden_launches"], "avg_launch_ms": h["hidden_avg_launch_ms"],
                                   "algorithmic_flops": "2 passes x 2 x (d_in h + 2 h^2) per state over the three hidden-layer launches "
@@ -920,6 +929,8 @@ def bench_nn(ctx, B, steps, warmup):
                                "K three times as deep); hidden_TFLOPs counts the algorithmic flops, the pipes execute 3 x that",
                           executed_hidden_TFLOPs=3.0 * s3["hidden_TFLOPs"], frac_of_bf16_peak_executed=3.0 * s3["hidden_TFLOPs"] / BF16_PEAK_TFLOPS,
                           speedup_over_f32=s3["states_per_s"] / f["states_per_s"])}
+    # BASELINE.json config 5 as literally written: RegulatorLayerWithUprev (568 inputs) at the same batch, f32 and bf16
+    out["with_uprev_568_inputs"] = bench_nn(ctx, B, max(2, steps // 2), 1, with_uprev=True, modes=("f32", "bf16"))
     return out
 
 

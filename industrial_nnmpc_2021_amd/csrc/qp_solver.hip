@@ -1531,6 +1531,12 @@ int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, co
   const int n = h->n, np = h->np, ka = h->ka, n_aug = h->n_aug;
   const int rp = ((r + 127) / 128) * 128;
   if (W <= 0 || W % 128 != 0 || W >= n || np % 128 != 0) { set_error("nnmpc_qp_set_farfield: W = %d must be a multiple of 128 below n = %d (padded %d)", W, n, np); return NNMPC_EINVAL; }
+  // the factored form costs 2 rp (ka + W + columns beyond W) flops per problem, the dense form 2 (ka + W)(columns beyond W): refuse
+  // factors that do not pay (a generic Hessian's far block has full rank; the MPC structure is what makes it ~Nx)
+  if ((double)rp * (ka + W + (np - W)) > 0.8 * (double)(ka + W) * (np - W)) {
+    set_error("nnmpc_qp_set_farfield: rank %d does not pay against the dense form at W = %d (n = %d, n_aug = %d)", r, W, n, n_aug);
+    return NNMPC_EINVAL;
+  }
   if (rp > np) { set_error("nnmpc_qp_set_farfield: rank %d too large for the workspace", r); return NNMPC_EINVAL; }
   const int nf = np - W;                                  // rows of the far block (padding rows: zero)
   std::vector<double> u((size_t)nf * rp, 0.0), vx((size_t)rp * ka, 0.0), vl((size_t)rp * W, 0.0), cu(nf / 128, 0.0);

@@ -112,6 +112,9 @@ class BatchedBoxQP:
         M = np.hstack((Kunc[W:], -Hinv[W:, :W]))
         U, s, Vt = sla.svd(M, full_matrices=False, lapack_driver="gesdd")
         r = max(1, int((s > rtol * s[0]).sum()))
+        rp, nf, k = -(-r // 128) * 128, self.n - W, -(-self.n_aug // 32) * 32 + W
+        if rp * (k + nf) > 0.8 * k * nf:             # the factored form would not pay (the library refuses such factors too):
+            return 0                                 # a generic Hessian's far block has full rank, the MPC structure makes it ~Nx
         Uf = np.ascontiguousarray(U[:, :r] * s[:r])
         Vx, Vl = np.ascontiguousarray(Vt[:r, :self.n_aug]), np.ascontiguousarray(Vt[:r, self.n_aug:])
         p = lambda a: a.ctypes.data_as(C.c_void_p)

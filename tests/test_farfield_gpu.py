@@ -41,10 +41,13 @@ def test_factors_are_verified_and_bad_ones_refused():
     assert 0 < r <= tq.shape[1] + 8                   # numerical rank ~ the (augmented) state dimension, far below n_aug + W
     assert qp.prepare_farfield(200) == 0 and qp.prepare_farfield(n) == 0     # not a window the pass can use
     rng = np.random.default_rng(0)
-    U, Vx, Vl = rng.standard_normal((n - 128, 4)), rng.standard_normal((4, tq.shape[1])), rng.standard_normal((4, 128))
+    U, Vx, Vl = rng.standard_normal((n - 384, 4)), rng.standard_normal((4, tq.shape[1])), rng.standard_normal((4, 384))
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = _lib.load().nnmpc_qp_set_farfield(qp._h, 128, 4, p(U), p(Vx), p(Vl))
-    assert rc == _lib.EINVAL and b"not usable" in _lib.load().nnmpc_last_error()
+    rc = _lib.load().nnmpc_qp_set_farfield(qp._h, 384, 4, p(U), p(Vx), p(Vl))
+    assert rc == _lib.EINVAL and b"not usable" in _lib.load().nnmpc_last_error()        # max |U V' - M| is checked on the device
+    U, Vx, Vl = rng.standard_normal((n - 384, 700)), rng.standard_normal((700, tq.shape[1])), rng.standard_normal((700, 384))
+    rc = _lib.load().nnmpc_qp_set_farfield(qp._h, 384, 700, p(U), p(Vx), p(Vl))
+    assert rc == _lib.EINVAL and b"does not pay" in _lib.load().nnmpc_last_error()      # ... and so is whether the rank is worth it
     qp.close()
 
 
@@ -119,3 +122,73 @@ def test_bound_violated_beyond_the_window_is_found_in_first_move_calls():
     assert ok.mean() > 0.95
     assert np.abs(a["u"][ok] - b["u"][ok]).max() < 1e-10 and np.array_equal(c["u"][ok], b["u"][ok][:, :nu])
     dense.close(); far.close()
+
+
+def test_far_violation_is_found_by_the_far_field_pass_and_never_skipped():
+    """Re-entry through the far-field form: the far block has rank 5 here (few columns of tq, one coupling in P); a bound far beyond
+    the column window is violated only once an early bound is clamped.  The pass must find it in sequence calls and in first-move
+    calls (|U_f| |T_p| >= |x_f| > the slack: the tile is evaluated), and the problem goes back into the rounds."""
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    from oracle import qp as oqp
+    n, nu, n_aug = 2048, 8, 200                       # (many columns of tq, most of them zero: the dense form's k-range is long,
+    P = np.eye(n)                                     # the far block's rank stays 5 -- the factored form pays)
+    f = n - 3
+    P[0, f] = P[f, 0] = -0.8
+    rng = np.random.default_rng(3)
+    tq = np.zeros((n, n_aug))
+    tq[0, 0] = 1.0; tq[f, 1] = 1.0
+    tq[:, 2:4] = 0.01 * rng.standard_normal((n, 2))
+    B = 6
+    x0 = 0.01 * rng.standard_normal((B, n_aug))
+    x0[:, :4] += np.array([-4.28, 3.1, 0.3, -0.2])
+    x0[B - 1] = 0.0                                   # one sample with nothing active at all
+    lb, ub = -np.ones((B, nu)), np.ones((B, nu))
+    qp = BatchedBoxQP(P, tq, nu, method="asm", max_batch=128, asm_tail_batch=-1, farfield="auto")
+    first = qp.solve_batch(x0, lb, ub)                # dense form; factors the window afterwards
+    assert qp._ff_done                                # (the window here is 128 columns)
+    qp.stats(reset=True)
+    out = qp.solve_batch(x0, lb, ub)
+    assert qp.stats()["asm_far_passes"] >= 1
+    fm = qp.solve_batch(x0, lb, ub, first_move_only=True)
+    assert (out["status"] == 0).all() and np.array_equal(out["active"], first["active"]) and np.array_equal(fm["active"], out["active"])
+    assert np.array_equal(fm["u"], out["u"][:, :nu])
+    for b in range(B):
+        info = {"nu": nu}
+        xe = oqp.solve_exact_box(P, tq @ x0[b], np.tile(lb[b], n // nu), np.tile(ub[b], n // nu), info=info)
+        ref = np.zeros(2 * n, bool); ref[info["active"]] = True
+        assert np.abs(out["u"][b] - xe).max() <= 1e-10 and np.array_equal(out["active"][b], ref)
+    assert abs(out["u"][0, 0] - 1.0) < 1e-12 and abs(out["u"][0, f] + 1.0) < 1e-12 and not out["active"][B - 1].any()
+    qp.close()
+
+
+def test_generic_hessian_far_block_does_not_pay_and_is_left_dense():
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    n, nu = 1024, 8
+    rng = np.random.default_rng(1)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    P = (Q * np.exp(rng.uniform(0, np.log(50.0), n))) @ Q.T
+    qp = BatchedBoxQP(P, np.eye(n), nu, method="asm", max_batch=128, farfield="auto")
+    assert qp.prepare_farfield(256) == 0              # full rank: the factored form would cost more than the dense one
+    qp.close()
+
+
+def test_warm_started_lock_step_batch_with_far_field():
+    """A batch of > 256 problems with an active-set guess (the chains' warm start at scale): the rounds start on the guess, x_unc
+    exists for the first 512 columns only and is extended when a guess reaches further; results equal the cold solve's."""
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    pl, P, tq, nu = _mid()
+    B = 1200
+    x0, lb, ub = _batch(pl, B, 31, 2.5)
+    qp = BatchedBoxQP(P, tq, nu, max_batch=512, farfield="auto")
+    cold = qp.solve_batch(x0, lb, ub)
+    assert (cold["status"] == 0).all()
+    guess = qp.active_to_state(cold["active"])
+    shifted = np.concatenate((guess[:, nu:], guess[:, -nu:]), axis=1)        # the chains' shift by one stage
+    shifted[::7, 900:916] = 1                                                # ... and some wrong guesses far out: the window grows
+    for g in (guess, shifted):
+        warm = qp.solve_batch(x0, lb, ub, guess=g)
+        assert np.array_equal(warm["status"], cold["status"]) and np.array_equal(warm["active"], cold["active"])
+        assert np.abs(warm["u"] - cold["u"]).max() < 1e-10
+        fm = qp.solve_batch(x0, lb, ub, guess=g, first_move_only=True)
+        assert np.array_equal(fm["active"], cold["active"]) and np.abs(fm["u"] - cold["u"][:, :nu]).max() < 1e-10
+    qp.close()
