@@ -67,10 +67,10 @@ typedef struct {
   int32_t method;            /* 0 = auto: shared-inverse active-set pass (needs nnmpc_qp_set_inverse),
                                 PDIP for what it leaves; 1 = PDIP only; 2 = active-set pass only */
   int32_t asm_max_active;    /* active-set pass: largest active set handled (<= 768); 0 = 768 */
-  int32_t asm_max_rounds;    /* ... and its budget; 0 = 200 lock-step rounds (all-at-once exchanges settle in ~5) and 4000
+  int32_t asm_max_rounds;    /* ... and its budget; 0 = 200 lock-step rounds (all-at-once exchanges settle in ~5) and 50 000
                                 iterations per problem in the device tail (the single-exchange fallback against cycling is
-                                finite but can take thousands of ~30 us iterations on ill-conditioned Hessians with half of
-                                the bounds active); > 0: that many of either; what is left goes to the PDIP path */
+                                finite but can take tens of thousands of ~30 us iterations on ill-conditioned Hessians with
+                                half of the bounds active); > 0: that many of either; what is left goes to the PDIP path */
   int32_t asm_f32_rounds;    /* 0 = the rounds run in f32 until a problem's set settles, then in fp64 (only fp64
                                 results are accepted); < 0 = fp64 from the first round */
   int32_t seg_max;           /* problems per segment (one lock-step pass; ~0.3 MB of workspace each at n = 4480);

@@ -1290,10 +1290,11 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   if (o.asm_max_active <= 0) o.asm_max_active = 768;
   if (o.asm_max_active > 768) o.asm_max_active = 768;
   o.asm_max_active = std::max(16, (o.asm_max_active / 16) * 16);
-  // the device tail (asm_tail_k) gets 4000 iterations unless the caller set a budget: Murty's rule is finite but slow on dense
-  // Hessians with cond >= 1e5 and half the bounds active -- scripts/stress_asm.py seed 3: 166 of 1567 problems unfinished after
-  // 200 iterations, 59 after 1000, 1 after 4000, at +10 % run time; the reference's own problems settle within 40
-  h->asm_tail_budget = o.asm_max_rounds <= 0 ? 4000 : o.asm_max_rounds;
+  // the device tail (asm_tail_k) gets 50 000 iterations unless the caller set a budget: Murty's rule is finite but slow on dense
+  // Hessians with cond >= 1e5 and half the bounds active -- scripts/stress_asm.py, seeds 1 and 3: 130 and 166 of ~1600 problems
+  // unfinished after 200 iterations, 27 and 1 after 4000, none after 30 000 (a straggler then holds one workgroup for ~1 s; the
+  // problems of the reference's regime settle within 40 iterations and never see the difference)
+  h->asm_tail_budget = o.asm_max_rounds <= 0 ? 50000 : o.asm_max_rounds;
   if (o.asm_max_rounds <= 0) o.asm_max_rounds = 200;
   if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;

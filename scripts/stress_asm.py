@@ -1,49 +1,104 @@
-"""Random generic box QPs of many shapes through the default path, checked against the fp64 oracle."""
-import sys, os, time
+"""Random generic box QPs of many shapes through the default path, checked against the fp64 oracle.
+
+    python scripts/stress_asm.py [seed] [cases]          METHOD=auto|asm|pdip, ASM_MAX_ROUNDS=<n> override the drawn settings
+
+Dense random Hessians with cond up to 1e6, 1 .. 16 inputs per stage, horizons up to 90, batches of 1 .. 130 problems, bounds drawn
+per problem: far from the reference's regime (MPC Hessians, 1-3 % of the bounds active) on purpose -- half of all bounds active at
+cond 5e5 is where the exchange rules need their anti-cycling fallback and tens of thousands of single exchanges.
+tests/test_stress_gpu.py runs seeds 0-3 (6403 problems) and demands every one certified and equal to the oracle.
+"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
-from oracle import qp as oqp
+
 
 def spd(n, rng, cond):
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     ev = np.exp(rng.uniform(0.0, np.log(cond), n))
     return (Q * ev) @ Q.T
 
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-nfail = ntot = 0
-t0 = time.time()
-for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-    nu = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 16]))
-    N = int(rng.integers(2, 90))
-    n = nu * N
-    if n > 700: N = 700 // nu; n = nu * N
-    cond = float(10 ** rng.uniform(0, 6))
-    P = spd(n, rng, cond)
-    n_aug = int(rng.integers(1, 12))
-    tq = rng.standard_normal((n, n_aug)) * np.sqrt(np.diag(P))[:, None] * rng.uniform(0.1, 3.0)
-    B = int(rng.choice([1, 3, 17, 64, 130]))
-    x0 = rng.standard_normal((B, n_aug)) * rng.uniform(0.2, 3.0)
-    if B > 2: x0[1] = 0.0                                   # trivial problem
-    lb = -rng.uniform(0.2, 2.0, (B, nu)); ub = rng.uniform(0.2, 2.0, (B, nu))
-    method = str(rng.choice(["auto", "asm", "asm"]))
-    method = os.environ.get("METHOD", method)
-    f32 = int(rng.choice([0, -1]))
-    qp = BatchedBoxQP(P, tq, nu, max_batch=128, method=method, asm_f32_rounds=f32, seg_max=int(rng.choice([0, 128])),
+
+def cases(seed, ncases=40):
+    """The script's problem stream: one dict per case (P, tq, nu, N, x0, lb, ub, method, solver options)."""
+    rng = np.random.default_rng(seed)
+    for case in range(ncases):
+        nu = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 16]))
+        N = int(rng.integers(2, 90))
+        n = nu * N
+        if n > 700:
+            N = 700 // nu
+            n = nu * N
+        cond = float(10 ** rng.uniform(0, 6))
+        P = spd(n, rng, cond)
+        n_aug = int(rng.integers(1, 12))
+        tq = rng.standard_normal((n, n_aug)) * np.sqrt(np.diag(P))[:, None] * rng.uniform(0.1, 3.0)
+        B = int(rng.choice([1, 3, 17, 64, 130]))
+        x0 = rng.standard_normal((B, n_aug)) * rng.uniform(0.2, 3.0)
+        if B > 2:
+            x0[1] = 0.0                                   # trivial problem
+        lb = -rng.uniform(0.2, 2.0, (B, nu))
+        ub = rng.uniform(0.2, 2.0, (B, nu))
+        method = str(rng.choice(["auto", "asm", "asm"]))
+        f32 = int(rng.choice([0, -1]))
+        seg = int(rng.choice([0, 128]))
+        yield dict(case=case, P=P, tq=tq, nu=nu, N=N, n=n, n_aug=n_aug, cond=cond, B=B, x0=x0, lb=lb, ub=ub,
+                   method=os.environ.get("METHOD", method), f32=f32, seg_max=seg)
+
+
+def solve_case(c):
+    """(outputs of BatchedBoxQP.solve_batch, stats) of one case on the GPU."""
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    qp = BatchedBoxQP(c["P"], c["tq"], c["nu"], max_batch=128, method=c["method"], asm_f32_rounds=c["f32"], seg_max=c["seg_max"],
                       asm_max_rounds=int(os.environ.get("ASM_MAX_ROUNDS", "0")))
-    out = qp.solve_batch(x0, lb, ub)
+    out = qp.solve_batch(c["x0"], c["lb"], c["ub"])
     st = qp.stats()
-    bad = []
-    for b in range(B):
-        info = {"nu": nu}
-        xe = oqp.solve_exact_box(P, tq @ x0[b], np.tile(lb[b], N), np.tile(ub[b], N), info=info)
-        act = np.zeros(2 * n, bool); act[info["active"]] = True
+    qp.close()
+    return out, st
+
+
+def oracle_row(args):
+    P, q, lb, ub, nu, N = args
+    from oracle import qp as oqp
+    info = {"nu": nu}
+    xe = oqp.solve_exact_box(P, q, np.tile(lb, N), np.tile(ub, N), info=info)
+    return xe, info["active"]
+
+
+def check_case(c, out, max_rows=None):
+    """[(row, status, relative error, active-set mismatches, size of the exact active set)] of the rows that are not certified
+    (every row is looked at), or -- among the first max_rows rows, all of them by default -- off the exact optimum by more than
+    1e-7 max(1, cond / 1e3) or with a different active set."""
+    n, B = c["n"], c["B"]
+    rows = range(B if max_rows is None else min(B, max_rows))
+    sols = [oracle_row((c["P"], c["tq"] @ c["x0"][b], c["lb"][b], c["ub"][b], c["nu"], c["N"])) for b in rows]
+    tol = 1e-7 * max(1.0, c["cond"] / 1e3)
+    bad = [(b, int(out["status"][b]), float("nan"), -1, -1) for b in range(len(sols), B) if out["status"][b] != 0]
+    for b, (xe, active) in enumerate(sols):
+        act = np.zeros(2 * n, bool)
+        act[active] = True
         err = np.abs(out["u"][b] - xe).max() / max(1.0, np.abs(xe).max())
-        tol = 1e-7 * max(1.0, cond / 1e3)
         if out["status"][b] != 0 or err > tol or not (out["active"][b] == act).all():
             bad.append((b, int(out["status"][b]), float(err), int((out["active"][b] != act).sum()), int(act.sum())))
-    ntot += B; nfail += len(bad)
-    print(f"case {case}: n={n} nu={nu} n_aug={n_aug} cond={cond:.1e} B={B} {method} f32={f32} asm_solved={st['asm_solved']} "
-          f"rounds={st['asm_rounds']} full_checks={st['asm_full_checks']} -> {'OK' if not bad else bad[:4]}", flush=True)
-    qp.close()
-print("problems", ntot, "failures", nfail, "time", round(time.time() - t0, 1))
+    return bad
+
+
+if __name__ == "__main__":
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    nfail = ntot = 0
+    tg = to = 0.0
+    t0 = time.time()
+    for c in cases(seed, int(sys.argv[2]) if len(sys.argv) > 2 else 40):
+        t1 = time.time()
+        out, st = solve_case(c)
+        t2 = time.time()
+        bad = check_case(c, out)
+        tg += t2 - t1
+        to += time.time() - t2
+        ntot += c["B"]
+        nfail += len(bad)
+        print(f"case {c['case']}: n={c['n']} nu={c['nu']} n_aug={c['n_aug']} cond={c['cond']:.1e} B={c['B']} {c['method']} f32={c['f32']} "
+              f"asm_solved={st['asm_solved']} rounds={st['asm_rounds']} full_checks={st['asm_full_checks']} -> {'OK' if not bad else bad[:4]}", flush=True)
+    print("problems", ntot, "failures", nfail, "time", round(time.time() - t0, 1), "gpu", round(tg, 1), "oracle", round(to, 1))
