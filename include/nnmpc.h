@@ -115,6 +115,7 @@ typedef struct {
   int64_t asm_far_passes;    /* full-width passes that ran in the far-field form (nnmpc_qp_set_farfield) */
   double asm_side_ms;        /* hipEvent time of the multiplier kernels of the larger sets on the three side streams (they run
                                 beside asm_lambda_reg32_k / asm_lambda_reg_k; sum over the streams) */
+  int64_t asm_small_passes;  /* segments that went through the one-wave-per-problem kernel of small problems (asm_small_k: n <= 724) */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);

@@ -30,7 +30,8 @@ class QpStats(C.Structure):
                 ("asm_lambda_bytes", C.c_double), ("asm_e1max", C.c_double),
                 ("asm_e2max", C.c_double), ("asm_full_checks", C.c_int64), ("asm_lambda32_ms", C.c_double),
                 ("asm_lambda64_ms", C.c_double), ("asm_lambda32_flops", C.c_double),
-                ("asm_lambda32_launches", C.c_int64), ("asm_lambda64_launches", C.c_int64), ("asm_far_passes", C.c_int64), ("asm_side_ms", C.c_double)]
+                ("asm_lambda32_launches", C.c_int64), ("asm_lambda64_launches", C.c_int64), ("asm_far_passes", C.c_int64), ("asm_side_ms", C.c_double),
+                ("asm_small_passes", C.c_int64)]
 
 
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",

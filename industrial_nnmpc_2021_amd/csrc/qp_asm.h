@@ -81,6 +81,7 @@ struct AsmDev {
   const double* ffVx;              // [ffr][ka]
   const double* ffVl;              // [ffr][ffW]  (minus sign of the Pinv block included)
   const double* ffcu;              // [(np - ffW) / 128] bound on |U_j| over all columns at or beyond each 128-column tile
+  const int* ffk;                  // [(np - ffW) / 128] columns of U the tile's rows use (staircase: zero from there on), multiple of 16
   int ffr, ffW;                    // padded rank (multiple of 128), the window the factors belong to
   double* T;                       // [row tiles * 128][ffr]
   double *tnorm, *tslack;          // [row tiles * 128] |T_p| and min_k min(ub_k, -lb_k) (first-move calls)
@@ -802,44 +803,20 @@ __device__ unsigned long long asm_stamp_buf[64];
 #define ASM_STAMP(i) do { } while (0)
 #endif
 
-template <class T, int MB, int WPB>
-__device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg) {
+// The solve of one wave, shared by the round kernels (asm_lambda_reg) and the fused small-problem kernel (asm_small_k):
+// gather -S = -H_AA from the index list ix[0 .. 16 MB) (LDS; entries beyond m repeat the last index), blocked Cholesky with the
+// forward substitution riding along, backward substitution.  rv: right-hand side [16 MB] (zero beyond m).  lam[I] receives the
+// multiplier of bound 16 I + li (every lane row holds a copy).  Returns non-zero (lam untouched) when S is not positive
+// definite in this precision.  lt: base of the LDS-resident tiles of this wave PLUS lane.
+template <class T, int MB>
+__device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* ix, T* dt, T* Yt, T* ys, const T* rv, T* lt, const T* idt,
+                                            T (&lam)[MB], int lane, int wg, int wave) {
   using N = AsmNum<T>;
   using V4 = typename N::v4;
   constexpr int NL = asm_nl<T>(MB);
-  extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  T* dt = reinterpret_cast<T*>(sm_raw) + (size_t)wave * asm_rw<T>(MB);   // diagonal tile, row-major stride 17
-  T* Yt = dt + ASM_TS;                                     // its inverse factor
-  T* ys = Yt + ASM_TS;                                     // y (forward result), [MB][16]
-  T* rv = ys + MB * 16;                                    // right-hand side, [MB][16]
-  T* lt = rv + MB * 16 + lane;                             // LDS-resident tiles: slot * 256 + r * 64 (+ lane)
-  T* idt = reinterpret_cast<T*>(sm_raw) + (size_t)WPB * asm_rw<T>(MB);   // identity tile (every wave writes all of it: same
-  for (int i = lane; i < ASM_TS; i += 64) idt[i] = (i / 17 == i % 17) ? T(1) : T(0);   // values, so no barrier is needed)
   auto slot = [](int I, int J) { return J * (MB - 1) - J * (J - 1) / 2 + I - J - 1; };   // tile (I,J), J < NL, I > J
-  const int nitem = d.counters[asm_list_counter(list)];
-  const int it = wg * WPB + wave;
-  if (it >= nitem) return;
-  const int p = __builtin_amdgcn_readfirstlane(d.binlist[(size_t)list * d.nseg + it]);
-  const size_t o = (size_t)p * d.np;
-  const unsigned char* st = d.st + (size_t)p * d.n;
-  const int* idx = d.idxg + (size_t)p * d.max_active;
-  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
-  if (m <= 0) return;
-  ASM_STAMP(0);
-  // ---- active indices and rhs -> LDS (read back block by block: registers are the scarce resource here).  The index
-  // list goes through LDS because every later use of an index is the ADDRESS of a gather: read from global memory it
-  // would sit in the same in-order vmcnt queue as the gathers before it, and each block column of the gather would
-  // wait for all the loads of the previous one (measured: 26 k of the wave's 85 k cycles went into ISSUING the gather).
-  int* ix = reinterpret_cast<int*>(ys);                    // [MB * 16] (ys is not written before the factorisation)
-  for (int i = lane; i < MB * 16; i += 64) {
-    const int a = idx[min(i, m - 1)], k = a % d.nu;
-    ix[i] = a;
-    const double v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
-    rv[i] = i < m ? (T)v : T(0);
-  }
-  ASM_FENCE();
+  (void)wg; (void)wave;
   // ---- gather: t(I,J)[r] = -S[16 I + li][16 J + kr(lq, r)], read as Pinv[row of (J, lq, r)][col of (I, li)].
   // The not yet factored tiles hold MINUS the Schur complement, so the trailing update is a plain
   // accumulation (the MFMAs have no negate modifier; a VALU negation would cost a pass over the operands).
@@ -975,16 +952,9 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
     }
   });
   ASM_STAMP(40);
-  if (bad) {
-    // f32: S is not positive definite in this precision -- this round is void (asm_update_k skips the problem,
-    // its LAM row is still zero), the next one runs in fp64.  fp64: hand the problem to the PDIP path.
-    if (lane == 0) { if (N::F32) { d.prec[p] = 1; d.redo[p] = 1; } else d.state[p] = ASM_FALLBACK; }
-    return;
-  }
-  if (!N::F32 && lane == 0) d.prec[p] = 1;                 // solved in fp64 (sets beyond the f32 classes start here)
+  if (bad) return 1;
   ASM_FENCE();
   // ---- backward substitution  L' lam = y
-  T lam[MB];
 #pragma unroll
   for (int K = MB - 1; K >= 0; --K) {
     T part = T(0);
@@ -1001,6 +971,53 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
     lam[K] = xsum4<T>(part);
     __builtin_amdgcn_sched_barrier(0);
   }
+  return 0;
+}
+
+template <class T, int MB, int WPB>
+__device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg) {
+  using N = AsmNum<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  T* dt = reinterpret_cast<T*>(sm_raw) + (size_t)wave * asm_rw<T>(MB);   // diagonal tile, row-major stride 17
+  T* Yt = dt + ASM_TS;                                     // its inverse factor
+  T* ys = Yt + ASM_TS;                                     // y (forward result), [MB][16]
+  T* rv = ys + MB * 16;                                    // right-hand side, [MB][16]
+  T* lt = rv + MB * 16 + lane;                             // LDS-resident tiles: slot * 256 + r * 64 (+ lane)
+  T* idt = reinterpret_cast<T*>(sm_raw) + (size_t)WPB * asm_rw<T>(MB);   // identity tile (every wave writes all of it: same
+  for (int i = lane; i < ASM_TS; i += 64) idt[i] = (i / 17 == i % 17) ? T(1) : T(0);   // values, so no barrier is needed)
+  const int nitem = d.counters[asm_list_counter(list)];
+  const int it = wg * WPB + wave;
+  if (it >= nitem) return;
+  const int p = __builtin_amdgcn_readfirstlane(d.binlist[(size_t)list * d.nseg + it]);
+  const size_t o = (size_t)p * d.np;
+  const unsigned char* st = d.st + (size_t)p * d.n;
+  const int* idx = d.idxg + (size_t)p * d.max_active;
+  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
+  if (m <= 0) return;
+  ASM_STAMP(0);
+  // ---- active indices and rhs -> LDS (read back block by block: registers are the scarce resource here).  The index
+  // list goes through LDS because every later use of an index is the ADDRESS of a gather: read from global memory it
+  // would sit in the same in-order vmcnt queue as the gathers before it, and each block column of the gather would
+  // wait for all the loads of the previous one (measured: 26 k of the wave's 85 k cycles went into ISSUING the gather).
+  int* ix = reinterpret_cast<int*>(ys);                    // [MB * 16] (ys is not written before the factorisation)
+  for (int i = lane; i < MB * 16; i += 64) {
+    const int a = idx[min(i, m - 1)], k = a % d.nu;
+    ix[i] = a;
+    const double v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+    rv[i] = i < m ? (T)v : T(0);
+  }
+  ASM_FENCE();
+  T lam[MB];
+  const int bad = asm_reg_core<T, MB>(d, m, ix, dt, Yt, ys, rv, lt, idt, lam, lane, wg, wave);
+  if (bad) {
+    // f32: S is not positive definite in this precision -- this round is void (asm_update_k skips the problem,
+    // its LAM row is still zero), the next one runs in fp64.  fp64: hand the problem to the PDIP path.
+    if (lane == 0) { if (N::F32) { d.prec[p] = 1; d.redo[p] = 1; } else d.state[p] = ASM_FALLBACK; }
+    return;
+  }
+  if (!N::F32 && lane == 0) d.prec[p] = 1;                 // solved in fp64 (sets beyond the f32 classes start here)
   ASM_STAMP(41);
   using LT = typename std::conditional<N::F32, float, double>::type;   // f32 rounds: row of LAM32 (f32 GEMM)
   LT* lrow = (N::F32 ? (LT*)d.lam32 : (LT*)d.lam) + (size_t)d.row[p] * d.np;

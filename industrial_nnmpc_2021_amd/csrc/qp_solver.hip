@@ -29,6 +29,7 @@
 #include "gemm_kernels.h"
 #include "qp_asm.h"
 #include "qp_wide.h"
+#include "qp_small.h"
 #include "common.h"
 
 using namespace nnmpc;
@@ -675,7 +676,7 @@ struct nnmpc_qp {
   int asm_pool;
   double asm_e1max, asm_e2max;
   // far-field factorisations of the full-width pass (nnmpc_qp_set_farfield), one per window
-  struct Far { int W, r, rp; double *U, *Vx, *Vl, *cu; double efar; };
+  struct Far { int W, r, rp; double *U, *Vx, *Vl, *cu; int* kt; double ksum; double efar; };   // ksum: sum of kt over the column tiles
   std::vector<Far> far;
   std::vector<int> far_missing;   // windows of full-width passes that ran in the dense form for want of factors (handed out once each)
   double p_inf = 0.0;       // max row sum of |P|
@@ -691,7 +692,7 @@ struct nnmpc_qp {
   hipStream_t stream;
   hipStream_t stream2 = nullptr;     // side streams of the active-set rounds (large-set kernels: the families do not wait for each other)
   hipStream_t stream3 = nullptr, stream4 = nullptr;
-  int asm_tail_budget = 4000;        // iterations of asm_tail_k per problem
+  int asm_tail_budget = 50000;       // iterations of asm_tail_k per problem (set in nnmpc_qp_create)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
   bool profiling;
   std::vector<hipEvent_t> ev_pool;
@@ -933,7 +934,10 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   // window outgrow it): beyond them x_unc is one K segment of the full-width pass's GEMM (qp_wide.h).  Calls that go to
   // the device tail from the start, and shapes the fused kernel's tiles do not fit, form all of it.  q = tq x0 is only
   // formed for the rows that need the full check with P.
-  const bool lazy = h->np % 128 == 0 && !no_fuse && !no_lazy && !tail_only && (uint64_t)h->seg_max * h->ka * 8 < (1ull << 32);
+  // Small problems -- Pinv fits the 4 MB L2 of an XCD (n <= 724: the CSTRs size, 540) -- run the whole iteration in one wave each
+  // (qp_small.h); what that kernel hands back (sets beyond 64 bounds, problems still moving after its budget) carries on below.
+  const bool small = getenv("NNMPC_NO_SMALL") == nullptr && (size_t)h->np * h->np * 8 <= (4u << 20) && h->n <= ASM_SM_NMAX && h->np % 4 == 0;   // (the variable: A/B, tests of the rounds at small sizes)
+  const bool lazy = h->np % 128 == 0 && !no_fuse && !no_lazy && !tail_only && !small && (uint64_t)h->seg_max * h->ka * 8 < (1ull << 32);
   int Wx = h->np;
   if (lazy) Wx = std::min(h->np, guess_dev ? 512 : ((std::min(h->n, std::max(512, ((h->n / 4 + 127) / 128) * 128)) + 127) / 128) * 128);
   {
@@ -942,10 +946,11 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   }
   AsmDev a;
   a.Kunc = h->Kunc64; a.Wx = Wx;
-  a.ffU = a.ffVx = a.ffVl = a.ffcu = nullptr; a.ffr = a.ffW = 0; a.T = h->asm_xhw; a.tnorm = h->asm_tnorm; a.tslack = h->asm_tslack;
+  a.ffU = a.ffVx = a.ffVl = a.ffcu = nullptr; a.ffk = nullptr; a.ffr = a.ffW = 0; a.T = h->asm_xhw; a.tnorm = h->asm_tnorm; a.tslack = h->asm_tslack;
   a.ff_skip = 0; a.ff_err = 0.0;
   static const bool no_far = getenv("NNMPC_NO_FARFIELD") != nullptr;      // diagnostics: dense form of the full-width pass (A/B)
-  int wide_far_rp = 0, fft_prev = 0;                      // the last full-width pass ran in the far-field form with this padded rank
+  int wide_far_rp = 0, fft_prev = 0;
+  double wide_far_ksum = 0.0;                      // the last full-width pass ran in the far-field form with this padded rank
   a.n = h->n; a.np = h->np; a.nu = h->nu; a.nseg = nprob;
   a.max_active = h->opts.asm_max_active; a.max_rounds = h->opts.asm_max_rounds;
   a.bound_tol = h->opts.bound_tol; a.stat_tol = 1e-8; a.pscale = h->pscale;
@@ -969,6 +974,47 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   int prev_rows = 0;                                    // fp64 rows of the last round (of LAM): the problems that settled in them await the full-width check
   int kprev = 0, wide_cols = 0, fused_c0 = -1;
   HIPCHK(hipMemsetAsync(h->asm_counters, 0, ASM_NCNT * sizeof(int), s));
+  if (small) {
+    EvScope es(h, 4, 0.0);
+    // iterations of grace before single exchanges (the variable: diagnostics).  24, not the rounds' ASM_GRACE = 10: on the cond-4e7
+    // CSTRs-size plant block exchanges that stall for a dozen iterations mostly recover, and a problem sent to single exchanges
+    // early pays for it with hundreds of them -- 131 072 problems at sx = 3: 260 ms per step at 10, 78 at 16, 39 at 24, 40 at 40
+    // (the ones that truly cycle wait longer for the fallback: 146 ms at 100); the 10 000-problem batch: 47 -> 26 iterations at most
+    static const int g0 = getenv("NNMPC_SMALL_GRACE") ? atoi(getenv("NNMPC_SMALL_GRACE")) : ASM_SM_GRACE;
+    hipLaunchKernelGGL((asm_small_k<2, 4, 4>), dim3(nprob), dim3(64), asm_small_lds_bytes(2, h->n, h->nu), s, a, a.max_rounds, g0);
+    static const int mb2 = getenv("NNMPC_SMALL_MB") ? atoi(getenv("NNMPC_SMALL_MB")) : 7;   // (the variable: diagnostics, A/B of the second instance)
+    if (mb2 == 7) hipLaunchKernelGGL((asm_small_k<7, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(7, h->n, h->nu), s, a, a.max_rounds, g0);
+    else if (mb2 == 6) hipLaunchKernelGGL((asm_small_k<6, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(6, h->n, h->nu), s, a, a.max_rounds, g0);
+    else if (mb2 == 5) hipLaunchKernelGGL((asm_small_k<5, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(5, h->n, h->nu), s, a, a.max_rounds, g0);
+    else if (mb2 == 4) hipLaunchKernelGGL((asm_small_k<4, 2, 4>), dim3(nprob), dim3(64), asm_small_lds_bytes(4, h->n, h->nu), s, a, a.max_rounds, g0);
+    h->stats.asm_rounds += 1;
+    h->stats.asm_small_passes += 1;
+    static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations and set sizes per problem
+    if (trace) {
+      std::vector<int> rd(nprob), mg(nprob), stt(nprob);
+      HIPCHK(stream_sync(s));
+      hipMemcpy(rd.data(), h->asm_rounds, nprob * sizeof(int), hipMemcpyDeviceToHost);
+      hipMemcpy(mg.data(), h->asm_mg, nprob * sizeof(int), hipMemcpyDeviceToHost);
+      hipMemcpy(stt.data(), h->asm_state, nprob * sizeof(int), hipMemcpyDeviceToHost);
+      long sum = 0, sm = 0, big = 0, bigit = 0, left = 0; int mx = 0, mm = 0, mxbig = 0, hist[8] = {0};
+      for (int i = 0; i < nprob; ++i) {
+        sum += rd[i]; mx = std::max(mx, rd[i]); sm += mg[i]; mm = std::max(mm, mg[i]); left += stt[i] == ASM_RUN;
+        if (mg[i] > 32) { ++big; bigit += rd[i]; mxbig = std::max(mxbig, rd[i]); }
+        hist[std::min(7, rd[i] / 8)]++;
+      }
+      fprintf(stderr, "asm small: %d problems, iterations mean %.2f max %d, final sets mean %.1f max %d; sets > 32: %ld (iterations mean %.1f max %d); handed on %ld; iterations/8 histogram",
+              nprob, (double)sum / nprob, mx, (double)sm / nprob, mm, big, big ? (double)bigit / big : 0.0, mxbig, left);
+      for (int b = 0; b < 8; ++b) fprintf(stderr, " %d", hist[b]);
+      fprintf(stderr, "\n");
+#ifdef ASM_SM_PROF
+      unsigned long long tp[2][8];
+      hipMemcpyFromSymbol(tp, HIP_SYMBOL(asm_small_prof), sizeof tp);
+      for (int k = 0; k < 2; ++k)
+        fprintf(stderr, "  small instance %d clock sums: list %llu, rhs + solve %llu, x window %llu, signs %llu, exchange / loop %llu; iterations %llu\n", k, tp[k][0], tp[k][1], tp[k][2], tp[k][3], tp[k][5], tp[k][6]);
+      memset(tp, 0, sizeof tp); hipMemcpyToSymbol(HIP_SYMBOL(asm_small_prof), tp, sizeof tp);
+#endif
+    }
+  }
   if (tail_only) {
     // A call of at most 256 problems -- the lock-step chains of a task, a controller's single QP -- is finished on the
     // device from the start (asm_tail_k: count -> fp64 solve -> x over all columns -> exchange rule, one workgroup per
@@ -1009,10 +1055,10 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         a.ff_err = 0.0; a.ff_skip = 0; wide_far_rp = 0;
         if (ff) {
           // far-field form: T = [x0 | lamw] V, x[c0:] = T U'; first-move calls skip the column tiles |U_j| |T_p| certifies
-          a.ffU = ff->U; a.ffVx = ff->Vx; a.ffVl = ff->Vl; a.ffcu = ff->cu; a.ffr = ff->rp; a.ffW = ff->W;
+          a.ffU = ff->U; a.ffVx = ff->Vx; a.ffVl = ff->Vl; a.ffcu = ff->cu; a.ffk = ff->kt; a.ffr = ff->rp; a.ffW = ff->W;
           a.ff_err = h->p_inf * ff->efar;
           a.ff_skip = h->nout <= c0 && h->nout < h->n;
-          wide_far_rp = ff->rp;
+          wide_far_rp = ff->rp; wide_far_ksum = ff->ksum;
           h->stats.asm_far_passes += 1;
           hipLaunchKernelGGL(asm_wide_t_k, dim3(g64_grid(ntm, ff->rp / 128)), dim3(256), G64_LDS, s, a, ntm, ff->rp / 128);
           if (a.ff_skip) hipLaunchKernelGGL(asm_wide_tnorm_k, dim3((ntm * 128 + 3) / 4), dim3(256), 0, s, a, ntm);
@@ -1046,11 +1092,11 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         // (from the scans of this round's asm_bins: the problems asm_wide_k just handled, the sum of their last active index + 1)
         const double nw = cnt[ASM_CNT_WIDE + 1], ksum = cnt[ASM_CNT_WKSUM];
         if (wide_far_rp) {
-          // far-field form: T = z V (k = n_aug + own k-range) and x = T U' (k = rp) -- over all columns, or (first-move calls)
-          // over the 128 x 128 tiles the certificate did not cover (device count)
-          const double tiles = cnt[ASM_CNT_FFTILES] - fft_prev;
+          // far-field form: T = z V (k = n_aug + own k-range) and x = T U' (k = the column tile's share of the basis) -- over all
+          // columns, or (first-move calls) over the 128 x 128 tiles the certificate did not cover (device count of their k chunks)
+          const double chunks = cnt[ASM_CNT_FFTILES] - fft_prev;
           h->stats.asm_gemm_flops += 2.0 * wide_far_rp * (ksum + nw * h->ka) +
-                                     (a.ff_skip ? 2.0 * wide_far_rp * 128.0 * 128.0 * tiles : 2.0 * wide_far_rp * (double)wide_cols * nw);
+                                     (a.ff_skip ? 2.0 * G64_KC * 128.0 * 128.0 * chunks : 2.0 * 128.0 * wide_far_ksum * nw);
         } else {
           h->stats.asm_gemm_flops += 2.0 * wide_cols * (ksum + (lazy ? nw * h->ka : 0.0));   // (lazy: x_unc beyond the window is part of that pass)
         }
@@ -1069,7 +1115,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       }
     }
     if (nrun == 0) break;
-    if (nrun <= std::min(h->asm_pool, 256) && rounds >= 6) {
+    if (nrun <= std::min(h->asm_pool, 256) && (rounds >= 6 || small)) {
       // the tail: a handful of stragglers (the bulk settles in 5-8 rounds) -- finish them on the device (asm_tail_k)
       // instead of paying eight launches and a read-back per round for them.  From round 6 on (12 before: at 100 000
       // problems per call the rounds 7..12 were launches for a few dozen problems, 5 % of the step)
@@ -1559,14 +1605,27 @@ int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, co
       cu[t] = run;
     }
   }
+  // staircase: columns of U a column tile's rows use at all (exact zeros beyond), in whole k chunks of the GEMM
+  std::vector<int> kt(nf / 128, 0);
+  double ksum = 0.0;
+  for (int t = 0; t < nf / 128; ++t) {
+    int last = 0;
+    for (int j = 128 * t; j < 128 * (t + 1); ++j)
+      for (int i = rp - 1; i >= last; --i)
+        if (u[(size_t)j * rp + i] != 0.0) { last = i + 1; break; }
+    kt[t] = ((last + G64_KC - 1) / G64_KC) * G64_KC;
+    ksum += kt[t];
+  }
   nnmpc_qp::Far f;
-  f.W = W; f.r = r; f.rp = rp; f.U = f.Vx = f.Vl = f.cu = nullptr; f.efar = 0.0;
+  f.W = W; f.r = r; f.rp = rp; f.U = f.Vx = f.Vl = f.cu = nullptr; f.kt = nullptr; f.ksum = ksum; f.efar = 0.0;
   int rc = 0;
   if (!rc) rc = dev_alloc(h, &f.U, u.size());
   if (!rc) rc = dev_alloc(h, &f.Vx, vx.size());
   if (!rc) rc = dev_alloc(h, &f.Vl, vl.size());
   if (!rc) rc = dev_alloc(h, &f.cu, cu.size());
+  if (!rc) rc = dev_alloc(h, &f.kt, kt.size());
   if (rc) return rc;
+  HIPCHK(hipMemcpy(f.kt, kt.data(), kt.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(f.U, u.data(), u.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(f.Vx, vx.data(), vx.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(f.Vl, vl.data(), vl.size() * 8, hipMemcpyHostToDevice));

@@ -11,8 +11,11 @@
 //    With the one-time factorisation  M = U V'  (host, fp64 SVD, verified on the device: max |U V' - M| enters the
 //    certificate)
 //        T = [x0 | lam] V            asm_wide_t_k       rows x rp,    k = n_aug + the row block's k-range
-//        x[W:] = T U'                asm_wide_gemm_k<FAR>             k = rp = 256
-//    2.6 x fewer flops than the dense product at the CDU size -- the same numbers to rounding.
+//        x[W:] = T U'                asm_wide_gemm_k<FAR>             k = ffk[column tile] <= rp = 256
+//    2.6 x fewer flops than the dense product at the CDU size -- the same numbers to rounding.  The basis is ordered so that
+//    the coordinates a column tile still feels come first (the closed loop forgets its fast modes first: the row space of
+//    M[j:, :] shrinks with j); U is a staircase, and a tile's K loop ends where its rows of U do (CDU, W = 512: 103 of 256 on
+//    average over the 31 tiles).
 //    First-move calls (NNMPC_OUT_FIRST_MOVE: nothing beyond the window is delivered, only checked) skip every 128-column
 //    tile that Cauchy-Schwarz certifies:  |x_j| <= |U_j| |T_p| <= min(ub, -lb)  for all rows of the tile and all columns at or
 //    beyond it (|U_j| decays geometrically along the horizon: CDU, W = 512: all but the first ~6 of 31 tiles).
@@ -120,11 +123,16 @@ static __global__ __launch_bounds__(256, 2) void asm_wide_gemm_k(AsmDev d, int c
       const int row = m0 + (tid & 127);
       const int need = tid < 128 && !(d.ffcu[tn] * d.tnorm[row] <= d.tslack[row]);   // (a NaN needs the check)
       if (!__syncthreads_or(need)) return;
-      if (tid == 0) atomicAdd(&d.counters[ASM_CNT_FFTILES], 1);
     }
-    const G64Seg st{d.T + (size_t)m0 * d.ffr, (size_t)d.ffr, d.ffU + (size_t)(n0 - c0) * d.ffr, (size_t)d.ffr, d.ffr / G64_KC};
-    const G64Seg s1{d.T, 0, d.ffU, 0, 0};
-    g64_tile<false>(acc, st, s1, g64_sm);
+    // staircase factors: the rows of U of this column tile are zero from column ffk[tn] on (the far field forgets the fast modes
+    // first -- qp.py prepare_farfield orders the basis that way; nnmpc_qp_set_farfield finds the zeros): k = ffk[tn], not the rank
+    const int kk = d.ffk[tn];
+    if (d.ff_skip && tid == 0) atomicAdd(&d.counters[ASM_CNT_FFTILES], kk / G64_KC);
+    if (kk > 0) {
+      const G64Seg st{d.T + (size_t)m0 * d.ffr, (size_t)d.ffr, d.ffU + (size_t)(n0 - c0) * d.ffr, (size_t)d.ffr, kk / G64_KC};
+      const G64Seg s1{d.T, 0, d.ffU, 0, 0};
+      g64_tile<false>(acc, st, s1, g64_sm);
+    }
     wide_epilogue<false, true>(d, acc, m0, n0);
     return;
   }

@@ -21,6 +21,44 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p), _lib.HOST
 
 
+def _staircase(U0, tol, block=128, chunk=16):
+    """Rotate the basis of the far-field factors so that far column tiles use few coordinates.
+
+    U0 (rows of the far block x r).  The row space of the suffix U0[128 j:] shrinks as j grows -- the closed loop forgets its
+    fast modes first.  Going down the blocks, the coordinates (within the ones still in use) whose singular values over ALL the
+    remaining rows are below tol are moved behind the ones that stay (SVD of the suffix in the current basis; what is dropped is
+    small on every later row by construction, nothing is ever estimated from a weak block).  With the orthonormal G (r' x r) this
+    gives  U0 = U1 G,  U1[block j, k_j:] = 0  up to tol per dropping step: a staircase.  Returns (U1 with those entries set to
+    exact zeros, k_j rounded up to whole K chunks of the GEMM; G).  The library's GEMM stops a column tile's K loop at k_j
+    (nnmpc_qp_set_farfield finds the zeros), and its device check of U V' against M covers the truncation."""
+    import scipy.linalg as sla
+    nf, r = U0.shape
+    nb = -(-nf // block)
+    Rs = [None] * nb                                     # R factor of the suffix U0[128 j:], bottom-up (same singular values / row space)
+    below = np.zeros((0, r))
+    for j in range(nb - 1, -1, -1):
+        below = Rs[j] = sla.qr(np.vstack((U0[j * block:(j + 1) * block], below)), mode="r")[0][:r]
+    cur = np.eye(r)                                      # rows: the coordinates still in use
+    drops, kj = [], np.zeros(nb, int)
+    for j in range(nb):
+        if cur.shape[0]:
+            _, sv, vt = sla.svd(Rs[j] @ cur.T)           # (full: vt is square, the rows beyond the rank span what is dropped)
+            k = int((sv > tol).sum())
+            drops.append(vt[k:] @ cur)
+            cur = vt[:k] @ cur
+        else:
+            drops.append(np.zeros((0, r)))
+        kj[j] = cur.shape[0]
+    G = np.vstack([cur] + drops[:0:-1])                  # (what block 0 drops is below tol everywhere: not part of the factors)
+    if G.shape[0] == 0:
+        G = np.eye(1, r)
+    kj = np.minimum(-(-kj // chunk) * chunk, G.shape[0])
+    U1 = U0 @ G.T
+    for j in range(nb):
+        U1[j * block:(j + 1) * block, kj[j]:] = 0.0
+    return np.ascontiguousarray(U1), G
+
+
 class BatchedBoxQP:
     """Owns the device copies of (P, tq) and the solver workspace.
 
@@ -100,8 +138,8 @@ class BatchedBoxQP:
 
     def prepare_farfield(self, W, rtol=1e-13):
         """Factor M = [Kunc[W:] | -Hinv[W:, 0:W]] = U [Vx | Vl] (truncated SVD: singular values above rtol times the
-        largest; M has numerical rank ~Nx) and hand the factors to the library, which verifies them on the device.
-        Returns the rank, or 0 when W is not a window the full-width pass can use."""
+        largest; M has numerical rank ~Nx; basis rotated so that U is a staircase, see _staircase) and hand the factors to the
+        library, which verifies them on the device.  Returns the rank, or 0 when W is not a window the full-width pass can use."""
         if self._ff_src is None or W in self._ff_done:
             return 0
         self._ff_done.add(W)
@@ -115,8 +153,10 @@ class BatchedBoxQP:
         rp, nf, k = -(-r // 128) * 128, self.n - W, -(-self.n_aug // 32) * 32 + W
         if rp * (k + nf) > 0.8 * k * nf:             # the factored form would not pay (the library refuses such factors too):
             return 0                                 # a generic Hessian's far block has full rank, the MPC structure makes it ~Nx
-        Uf = np.ascontiguousarray(U[:, :r] * s[:r])
-        Vx, Vl = np.ascontiguousarray(Vt[:r, :self.n_aug]), np.ascontiguousarray(Vt[:r, self.n_aug:])
+        Uf, G = _staircase(U[:, :r] * s[:r], rtol * s[0])
+        r = G.shape[0]
+        Vt = G @ Vt[:G.shape[1]]
+        Vx, Vl = np.ascontiguousarray(Vt[:, :self.n_aug]), np.ascontiguousarray(Vt[:, self.n_aug:])
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         rc = self._lib.nnmpc_qp_set_farfield(self._h, W, r, p(Uf), p(Vx), p(Vl))
         if rc == _lib.EINVAL:                        # refused (rank too large for the workspace, factors too inaccurate): dense form stays
