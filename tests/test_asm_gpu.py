@@ -12,6 +12,13 @@ from oracle import qp as oqp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _rounds_not_the_small_kernels(monkeypatch):
+    """n = 512 here: small enough for the one-wave-per-problem kernels (qp_small.h), which would take these problems away from
+    the round kernels this file is about (tests/test_small_gpu.py covers those kernels, with and without this switch)."""
+    monkeypatch.setenv("NNMPC_NO_SMALL", "1")
+
+
 def _spd(n, seed, cond=50.0):
     rng = np.random.default_rng(seed)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))

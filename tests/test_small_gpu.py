@@ -1,0 +1,128 @@
+"""GPU parity tests of the one-wave-per-problem kernels of small problems (qp_small.h: asm_small_k), through the C ABI.
+
+The whole active-set iteration of a problem runs in one wave (sets of up to 32 bounds in the first instance, up to 112 in the
+second); larger sets and problems over the iteration budget are handed to the lock-step rounds / the device tail as they stand.
+Checked against the fp64 oracle (oracle/qp.py) and against the same call with the kernels switched off (NNMPC_NO_SMALL=1: the
+rounds of qp_asm.h): same status, same active sets, u equal to rounding.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import oracle_box_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(name, B, seed, sx):
+    """(P, tq, nu, N, x0, lb, ub) of a synthetic plant with the reference's tuning, inputs as get_control_sequence forms them."""
+    from industrial_nnmpc_2021_amd import synthetic
+    from industrial_nnmpc_2021_amd.linearMPC_build import build_regulator_matrices
+    pl = synthetic.plant(name, seed=0)
+    P, tq, nu = build_regulator_matrices(pl)
+    s = synthetic.samples(pl, B, seed=seed, sx=sx)
+    x0 = np.concatenate((s["x"] - s["xs"], s["uprev"] - s["us"]), axis=1)
+    return P, tq, nu, pl["N"], x0, np.ascontiguousarray(pl["ulb"].T - s["us"]), np.ascontiguousarray(pl["uub"].T - s["us"])
+
+
+def _oracle(P, tq, nu, N, x0, lb, ub, rows):
+    Ps = np.tril(P) + np.tril(P, -1).T
+    out = []
+    for xe, active in oracle_box_rows(Ps, tq, nu, N, x0, lb, ub, rows):
+        act = np.zeros(2 * P.shape[0], bool)
+        act[active] = True
+        out.append((xe, act))
+    return out
+
+
+def _both_ways(monkeypatch, make_qp, solve):
+    res = {}
+    for small in (True, False):
+        if small:
+            monkeypatch.delenv("NNMPC_NO_SMALL", raising=False)
+        else:
+            monkeypatch.setenv("NNMPC_NO_SMALL", "1")
+        qp = make_qp()
+        out = solve(qp)
+        res[small] = (out, qp.stats())
+        qp.close()
+    return res
+
+
+@pytest.mark.parametrize("name,B,sx", [("mini_cstrs", 300, 1.0), ("mini_cdu", 300, 2.0), ("cstrs", 1500, 2.0)])
+def test_small_kernels_equal_the_rounds_and_the_oracle(monkeypatch, name, B, sx):
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    P, tq, nu, N, x0, lb, ub = _problem(name, B, 5, sx)
+    res = _both_ways(monkeypatch, lambda: BatchedBoxQP(P, tq, nu, max_batch=512, method="asm"),
+                     lambda qp: qp.solve_batch(x0, lb, ub))
+    (a, sa), (b, sb) = res[True], res[False]
+    assert sa["asm_small_passes"] >= 1 and sb["asm_small_passes"] == 0
+    assert sa["asm_solved"] == B and sb["asm_solved"] == B and sa["factorizations"] == 0
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    assert (a["active"] == b["active"]).all()
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-9 * max(1.0, np.abs(b["u"]).max())
+    rows = list(range(0, B, max(1, B // 24)))
+    for r, (xe, act) in zip(rows, _oracle(P, tq, nu, N, x0, lb, ub, rows)):
+        assert (a["active"][r] == act).all(), r
+        assert np.abs(a["u"][r] - xe).max() <= 1e-7 * max(1.0, np.abs(xe).max())
+
+
+def test_sets_beyond_both_instances_are_handed_on(monkeypatch):
+    """CSTRs size at a wide spread: sets of 33 .. 112 bounds pass through the second instance, larger ones are handed to the rounds /
+    the device tail with their bound states and exchange-rule memory -- every problem certified, active sets as the rounds alone find."""
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    B = 2000
+    P, tq, nu, N, x0, lb, ub = _problem("cstrs", B, 11, 4.0)
+    res = _both_ways(monkeypatch, lambda: BatchedBoxQP(P, tq, nu, max_batch=2048, method="auto"),
+                     lambda qp: qp.solve_batch(x0, lb, ub))
+    (a, sa), (b, sb) = res[True], res[False]
+    nact = a["active"].sum(axis=1)
+    assert nact.max() > 112 and (nact > 32).sum() > 50 and (nact <= 32).sum() > 50          # all three routes are taken
+    assert (a["status"] == 0).all() and (b["status"] == 0).all()
+    assert (a["active"] == b["active"]).all()
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-8
+    rows = [int(np.argmax(nact)), int(np.argmin(nact)), 0, 1, 2]
+    for r, (xe, act) in zip(rows, _oracle(P, tq, nu, N, x0, lb, ub, rows)):
+        assert (a["active"][r] == act).all(), r
+        assert np.abs(a["u"][r] - xe).max() <= 1e-6 * max(1.0, np.abs(xe).max())
+
+
+def test_first_moves_guess_and_ragged_shapes(monkeypatch):
+    """First-move output, a caller's guess (warm start), a single problem, and an n that is no multiple of 64 or of 4 columns per lane."""
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    rng = np.random.default_rng(3)
+    nu, N = 3, 23                                       # n = 69
+    n = nu * N
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    P = (Q * np.exp(rng.uniform(0.0, np.log(200.0), n))) @ Q.T
+    tq = rng.standard_normal((n, 5)) * np.sqrt(np.diag(P))[:, None]
+    for B in (1, 77):
+        x0 = rng.standard_normal((B, 5)) * 1.5
+        lb, ub = -rng.uniform(0.3, 1.0, (B, nu)), rng.uniform(0.3, 1.0, (B, nu))
+        qp = BatchedBoxQP(P, tq, nu, max_batch=128, method="asm")
+        full = qp.solve_batch(x0, lb, ub)
+        assert qp.stats()["asm_small_passes"] >= 1 and (full["status"] == 0).all()
+        first = qp.solve_batch(x0, lb, ub, first_move_only=True)
+        assert np.array_equal(first["u"], full["u"][:, :nu]) and (first["active"] == full["active"]).all()
+        warm = qp.solve_batch(x0, lb, ub, guess=qp.active_to_state(full["active"]))
+        assert (warm["status"] == 0).all() and (warm["active"] == full["active"]).all()
+        assert np.abs(warm["u"] - full["u"]).max() <= 1e-10
+        qp.close()
+        for b in range(min(B, 6)):
+            from oracle import qp as oqp
+            info = {"nu": nu}
+            xe = oqp.solve_exact_box(P, tq @ x0[b], np.tile(lb[b], N), np.tile(ub[b], N), info=info)
+            act = np.zeros(2 * n, bool)
+            act[info["active"]] = True
+            assert (full["active"][b] == act).all() and np.abs(full["u"][b] - xe).max() <= 1e-8
+
+
+def test_invalid_inputs_are_rejected_as_before():
+    from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
+    P, tq, nu, N, x0, lb, ub = _problem("mini_cstrs", 8, 2, 1.0)
+    x0[3, 0] = np.nan
+    lb[5, 0] = ub[5, 0] + 1.0
+    qp = BatchedBoxQP(P, tq, nu, max_batch=128, method="asm")
+    out = qp.solve_batch(x0, lb, ub)
+    qp.close()
+    assert out["status"][3] == 2 and out["status"][5] == 2 and (np.delete(out["status"], [3, 5]) == 0).all()
+    assert np.isnan(out["u"][3]).all() and not out["active"][3].any()
