@@ -1030,7 +1030,20 @@ def main():
             out["chains_task"] = timed("chains_task", chains_task_leg, ctx, 149, 2400)
             cfg = {}
             t_cfg = time.perf_counter()
-            r2, h2 = bench_qp(ctx, "cstrs", 10000, max(args.steps, 5), 2, args.sx, want_buffers=True)
+            # (three handles, the fastest is reported, all three are listed: on this pool a handle created after others have come and
+            # gone sometimes sees ~16.7 ms added to every profiled call -- outside the library's own clock around the call, which
+            # reads 1.4 ms either way -- and a 1.4 ms step cannot hide that the way a 21 ms one does)
+            runs, r2, h2 = [], None, None
+            for _ in range(3):
+                rr, hh = bench_qp(ctx, "cstrs", 10000, max(args.steps, 5), 2, args.sx, want_buffers=True)
+                runs.append(rr["ms_per_step"])
+                if r2 is None or rr["ms_per_step"] < r2["ms_per_step"]:
+                    if h2 is not None:
+                        h2["qp"].close(); h2["buf"].free()
+                    r2, h2 = rr, hh
+                else:
+                    hh["qp"].close(); hh["buf"].free()
+            r2["ms_per_step_of_each_handle"] = runs
             r2["config"] = {"workload": "cstrs_offline_data: synthetic CSTRs-size plant (n=540, m=1080, cond(P) = 4e7), 10000 sampled x0, 1 GPU"}
             if not args.no_parity:
                 r2["parity"] = parity_leg(h2, 32, 2000)

@@ -404,7 +404,7 @@ int nnmpc_chain_reset(nnmpc_chain* c) {
     HIPCHK(hipMemcpyAsync(c->x + (size_t)k * c->nx, c->x0, c->nx * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->uprev + (size_t)k * c->nu, c->uprev0, c->nu * 8, hipMemcpyDeviceToDevice, c->stream));
   }
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(stream_sync(c->stream));
   c->have_guess = false;
   return NNMPC_OK;
 }
@@ -447,7 +447,7 @@ int nnmpc_chain_run(nnmpc_chain* c, int32_t T, const double* xs, const double* u
     const double* d_t = nd ? d_d + (size_t)t * nc * nd : nullptr;
     hipLaunchKernelGGL(chain_pre_k, dim3(nc), dim3(256), 0, c->stream, nx, nu, c->x, c->uprev, xs_t, us_t, c->ulb, c->uub,
                        c->qx0, c->lb, c->ub, xr_d + (size_t)t * nc * nx, ur_d + (size_t)t * nc * nu);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(stream_sync(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = nnmpc_qp_solve_batch_ex(c->qp, nc, c->qx0, c->lb, c->ub, (warm_start && c->have_guess) ? c->guess : nullptr,
                                            c->first, c->act, c->status, nullptr, NNMPC_DEVICE, NNMPC_OUT_FIRST_MOVE);
@@ -464,7 +464,7 @@ int nnmpc_chain_run(nnmpc_chain* c, int32_t T, const double* xs, const double* u
     c->have_guess = true;
   }
   HIPCHK(hipEventRecord(c->e1, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(stream_sync(c->stream));
   HIPCHK(hipGetLastError());
   float ms = 0.f;
   hipEventElapsedTime(&ms, c->e0, c->e1);
@@ -484,7 +484,7 @@ int nnmpc_qp_first_moves(const double* u, int64_t ldu, const double* us, int32_t
   const size_t total = (size_t)B * nu;
   const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(first_moves_k, dim3(grid), dim3(256), 0, 0, out, u, (size_t)ldu, us, B, nu);
-  HIPCHK(hipStreamSynchronize(0));
+  HIPCHK(stream_sync(0));      // (polling: common.h)
   return NNMPC_OK;
 }
 
@@ -595,7 +595,7 @@ int nnmpc_ts_solve_batch(nnmpc_ts* h, int32_t B, const double* q, const double* 
     if (active) HIPCHK(hipMemcpyAsync(active, ad, (size_t)B * nu, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(status, sd, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(stream_sync(h->stream));
   HIPCHK(hipGetLastError());
   return NNMPC_OK;
 }

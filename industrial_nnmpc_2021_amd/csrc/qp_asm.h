@@ -807,13 +807,13 @@ __device__ unsigned long long asm_stamp_buf[64];
 // gather -S = -H_AA from the index list ix[0 .. 16 MB) (LDS; entries beyond m repeat the last index), blocked Cholesky with the
 // forward substitution riding along, backward substitution.  rv: right-hand side [16 MB] (zero beyond m).  lam[I] receives the
 // multiplier of bound 16 I + li (every lane row holds a copy).  Returns non-zero (lam untouched) when S is not positive
-// definite in this precision.  lt: base of the LDS-resident tiles of this wave PLUS lane.
-template <class T, int MB>
+// definite in this precision.  lt: base of the LDS-resident tiles of this wave PLUS lane.  NL: block columns whose tiles live there.
+// MB >= 5 expects 16 (MB - 1) < m <= 16 MB (the size classes of the rounds) unless ANYM is set.
+template <class T, int MB, int NL = asm_nl<T>(MB), bool ANYM = false>
 __device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* ix, T* dt, T* Yt, T* ys, const T* rv, T* lt, const T* idt,
                                             T (&lam)[MB], int lane, int wg, int wave) {
   using N = AsmNum<T>;
   using V4 = typename N::v4;
-  constexpr int NL = asm_nl<T>(MB);
   const int li = lane & 15, lq = lane >> 4;
   auto slot = [](int I, int J) { return J * (MB - 1) - J * (J - 1) / 2 + I - J - 1; };   // tile (I,J), J < NL, I > J
   (void)wg; (void)wave;
@@ -845,7 +845,8 @@ __device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* i
           const HT v = *reinterpret_cast<const HT*>(Hbase + (rowoff + gco[I]));
           // a class of MB >= 5 blocks holds sets with 16 (MB - 1) < m <= 16 MB: only the last block row / column can
           // reach beyond m (padding = identity); the other tiles need no select
-          const bool edge = MB <= 4 || I == MB - 1;
+          // (ANYM: any m <= 16 MB -- every tile gets the select)
+          const bool edge = ANYM || MB <= 4 || I == MB - 1;
           const T e = !edge ? (T)(-v) : ((gi < m && gj < m) ? (T)(-v) : (gi == gj ? T(-1) : T(0)));
           if (J < NL && I > J) lt[slot(I, J) * 256 + r * 64] = e;
           else C[asm_tix(I, J)][r] = e;

@@ -14,7 +14,7 @@
 //     number keeps falling, ASM_GRACE iterations of grace, then Murty's least-index single exchanges), the certificate of
 //     asm_update_k (inverse-error bound, else ASM_DONE: asm_certify_k checks with P itself).
 // Two instances, launched one after the other over all problems of the segment (a wave whose problem is not running exits at once):
-//     asm_small_k<2, 4, 4>   sets of up to 32 bounds -- the common case (CSTRs batch: 17 on average) -- in at most 128 VGPRs: four
+//     asm_small_k<2, 3, 4>   sets of up to 32 bounds -- the common case (CSTRs batch: 17 on average) -- in at most 128 VGPRs: four
 //                         waves per SIMD hide the L2 round trips of the gathers (the iteration is a chain of them)
 //     asm_small_k<7, 1, 8>   sets of up to 112 bounds (28 accumulator tiles): the few problems the first instance handed back
 // A problem whose set outgrows an instance, or that is still moving after `budget` iterations, is handed back as it stands
@@ -28,10 +28,15 @@ namespace nnmpc {
 
 constexpr int ASM_SM_GRACE = 24;                 // iterations without a new minimum of infeasible indices before single exchanges (see solve_segment_asm)
 constexpr int ASM_SM_NMAX = 1024;                // largest n (x_unc, bound states and decisions of the problem live in LDS)
-// LDS bytes of a wave: dt, Yt | ys, rv [16 MB] | lamv [16 MB] doubles | al, ao [16 MB] ints | x_unc [nst] doubles | lb, ub [nu] |
-// st, dec [nst] bytes
+// Tiles of the first block columns kept in LDS instead of accumulator registers (asm_reg_core's NL), by set size in 16-blocks.
+// No instance of this kernel uses scratch memory: spilled registers would sit in the dependent chain of an iteration.
+__host__ __device__ constexpr int asm_small_nl(int mb) { return mb <= 3 ? 0 : (mb <= 5 ? 1 : (mb == 6 ? 2 : 5)); }
+__host__ __device__ constexpr int asm_small_nlt(int mb) { return asm_small_nl(mb) * (mb - 1) - asm_small_nl(mb) * (asm_small_nl(mb) - 1) / 2; }
+// LDS bytes of a wave: dt, Yt | ys, rv [16 MB] | lamv [16 MB] doubles | LDS-resident tiles | al, ao [16 MB] ints | x_unc [nst] doubles |
+// lb, ub [nu] | st, dec [nst] bytes
 __host__ __device__ constexpr int asm_small_lds_bytes(int mbmax, int n, int nu) {
-  return 2 * ASM_TS * 8 + 3 * 16 * mbmax * 8 + 2 * 16 * mbmax * 4 + (((n + 63) / 64) * 64) * 8 + 2 * (((nu + 1) / 2) * 2) * 8 + 2 * (((n + 63) / 64) * 64);
+  return 2 * ASM_TS * 8 + 3 * 16 * mbmax * 8 + asm_small_nlt(mbmax) * 256 * 8 + 2 * 16 * mbmax * 4 + (((n + 63) / 64) * 64) * 8 + 2 * (((nu + 1) / 2) * 2) * 8 +
+         2 * (((n + 63) / 64) * 64);
 }
 
 #ifdef ASM_SM_PROF
@@ -52,7 +57,8 @@ __global__ __launch_bounds__(64, OCC) void asm_small_k(AsmDev d, int budget, int
   double* ys = Yt + ASM_TS;                                  // [MS] forward result; the index list of the gather before that
   double* rv = ys + MS;                                      // [MS] right-hand side
   double* lamv = rv + MS;                                    // [MS] multipliers in list order
-  double* xul = lamv + MS;                                   // [nst] x_unc of the problem
+  double* ltl = lamv + MS;                                   // LDS-resident tiles of the larger sets (sized for MBMAX; smaller sets use a prefix)
+  double* xul = ltl + asm_small_nlt(MBMAX) * 256;            // [nst] x_unc of the problem
   double* lbl = xul + nst;                                   // [nu] its bounds
   double* ubl = lbl + nup;
   int* al = reinterpret_cast<int*>(ubl + nup);               // [MS] active indices, ascending
@@ -103,19 +109,21 @@ __global__ __launch_bounds__(64, OCC) void asm_small_k(AsmDev d, int budget, int
       ASM_FENCE();
       int bad = 0;
       const int mb = (m + 15) >> 4;
-      bool done = false;
-      asm_sfor<1, MBMAX + 1>([&](auto MBc) {
+      // (two instances of the solve per kernel: more of them in one kernel and the register allocator no longer fits the largest
+      // -- 60 .. 230 registers spilled to scratch with seven; up to four blocks every tile has the padding select, so a smaller
+      // set runs the larger instance with identity padding; the seven-block instance does the same with ANYM)
+      auto solve = [&](auto MBc, auto ANYc) {
         constexpr int MB = decltype(MBc)::value;
-        if (!done && (mb == MB || MB == MBMAX)) {            // (wave-uniform)
-          done = true;
-          double lam[MB];
-          bad = asm_reg_core<double, MB>(d, m, ix, dt, Yt, ys, rv, rv, (const double*)nullptr, lam, lane, 0, 0);
-          if (!bad) {
+        double lam[MB];
+        bad = asm_reg_core<double, MB, asm_small_nl(MB), (decltype(ANYc)::value != 0)>(d, m, ix, dt, Yt, ys, rv, ltl + lane, (const double*)nullptr, lam, lane, 0, 0);
+        if (!bad) {
 #pragma unroll
-            for (int I = 0; I < MB; ++I) { const int i = 16 * I + li; if (lq == 0 && i < m) lamv[i] = lam[I]; }
-          }
+          for (int I = 0; I < MB; ++I) { const int i = 16 * I + li; if (lq == 0 && i < m) lamv[i] = lam[I]; }
         }
-      });
+      };
+      if constexpr (MBMAX <= 2) { if (mb == 1) solve(asm_ic<1>{}, asm_ic<0>{}); else solve(asm_ic<2>{}, asm_ic<0>{}); }
+      else if constexpr (MBMAX <= 4) solve(asm_ic<4>{}, asm_ic<0>{});
+      else { if (mb <= 4) solve(asm_ic<4>{}, asm_ic<0>{}); else solve(asm_ic<MBMAX>{}, asm_ic<1>{}); }
       if (bad) { outcome = 2; break; }
       ASM_FENCE();
       const double md = (double)m;

@@ -694,6 +694,11 @@ struct nnmpc_qp {
   hipStream_t stream3 = nullptr, stream4 = nullptr;
   int asm_tail_budget = 50000;       // iterations of asm_tail_k per problem (set in nnmpc_qp_create)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_join4 = nullptr;
+  // pinned host copies of the active-set pass's read-backs (the round counters, the status of a segment): into pageable memory a
+  // "hipMemcpyAsync" is staged and waited for inside the runtime (a blocking wait); pinned, the copy is a packet on the stream and
+  // stream_sync polls for it.
+  int* pin_cnt = nullptr;            // [ASM_NCNT]
+  int* pin_st = nullptr;             // [seg_max]
   bool profiling;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used;
@@ -969,7 +974,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   if (!guess_dev) HIPCHK(hipMemsetAsync(h->asm_st, 0, (size_t)nprob * h->n, s));   // bound states: asm_init_k writes the leading window only
   hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
   const int lds_big = (a.max_active + ASM_TS) * 8;
-  int cnt[ASM_NCNT] = {0};
+  int* cnt = h->pin_cnt;
+  memset(cnt, 0, ASM_NCNT * sizeof(int));
   int rounds = 0;
   int prev_rows = 0;                                    // fp64 rows of the last round (of LAM): the problems that settled in them await the full-width check
   int kprev = 0, wide_cols = 0, fused_c0 = -1;
@@ -981,12 +987,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     // early pays for it with hundreds of them -- 131 072 problems at sx = 3: 260 ms per step at 10, 78 at 16, 39 at 24, 40 at 40
     // (the ones that truly cycle wait longer for the fallback: 146 ms at 100); the 10 000-problem batch: 47 -> 26 iterations at most
     static const int g0 = getenv("NNMPC_SMALL_GRACE") ? atoi(getenv("NNMPC_SMALL_GRACE")) : ASM_SM_GRACE;
-    hipLaunchKernelGGL((asm_small_k<2, 4, 4>), dim3(nprob), dim3(64), asm_small_lds_bytes(2, h->n, h->nu), s, a, a.max_rounds, g0);
-    static const int mb2 = getenv("NNMPC_SMALL_MB") ? atoi(getenv("NNMPC_SMALL_MB")) : 7;   // (the variable: diagnostics, A/B of the second instance)
-    if (mb2 == 7) hipLaunchKernelGGL((asm_small_k<7, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(7, h->n, h->nu), s, a, a.max_rounds, g0);
-    else if (mb2 == 6) hipLaunchKernelGGL((asm_small_k<6, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(6, h->n, h->nu), s, a, a.max_rounds, g0);
-    else if (mb2 == 5) hipLaunchKernelGGL((asm_small_k<5, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(5, h->n, h->nu), s, a, a.max_rounds, g0);
-    else if (mb2 == 4) hipLaunchKernelGGL((asm_small_k<4, 2, 4>), dim3(nprob), dim3(64), asm_small_lds_bytes(4, h->n, h->nu), s, a, a.max_rounds, g0);
+    hipLaunchKernelGGL((asm_small_k<2, 3, 4>), dim3(nprob), dim3(64), asm_small_lds_bytes(2, h->n, h->nu), s, a, a.max_rounds, g0);
+    hipLaunchKernelGGL((asm_small_k<7, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(7, h->n, h->nu), s, a, a.max_rounds, g0);
     h->stats.asm_rounds += 1;
     h->stats.asm_small_passes += 1;
     static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations and set sizes per problem
@@ -1247,8 +1249,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);
   }
   hipLaunchKernelGGL(asm_certify_k, dim3(nprob), dim3(256), 0, s, a, h->pscale);
-  std::vector<int> st(nprob);
-  HIPCHK(hipMemcpyAsync(st.data(), h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost, s));
+  int* st = h->pin_st;
+  HIPCHK(hipMemcpyAsync(st, h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(stream_sync(s));
   HIPCHK(hipGetLastError());
   std::vector<int> fb;
@@ -1258,8 +1260,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   if (st_dev) HIPCHK(hipMemcpyAsync(st_dev, h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (fb.empty()) { h->stats.problems += nprob; return 0; }
   if (h->opts.method == 2) {                           // asm only: report the rest as not certified
-    for (int& v : st) v = v == 3 ? NNMPC_ST_MAXITER : v;
-    if (st_dev) HIPCHK(hipMemcpy(st_dev, st.data(), (size_t)nprob * sizeof(int), hipMemcpyHostToDevice));
+    for (int p = 0; p < nprob; ++p) st[p] = st[p] == 3 ? NNMPC_ST_MAXITER : st[p];
+    if (st_dev) HIPCHK(hipMemcpy(st_dev, st, (size_t)nprob * sizeof(int), hipMemcpyHostToDevice));
     h->stats.problems += nprob;
     return 0;
   }
@@ -1416,6 +1418,8 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->q64_all, G * np); A_(h->uunc_all, G * np);
   A_(h->lb_d, G * nu); A_(h->ub_d, G * nu);
   A_(h->in_stage, G * n_aug);
+  if (!rc && hipHostMalloc((void**)&h->pin_cnt, ASM_NCNT * sizeof(int)) != hipSuccess) { set_error("nnmpc_qp_create: hipHostMalloc failed"); rc = NNMPC_EHIP; }
+  if (!rc && hipHostMalloc((void**)&h->pin_st, G * sizeof(int)) != hipSuccess) { set_error("nnmpc_qp_create: hipHostMalloc failed"); rc = NNMPC_EHIP; }
   A_(d.lb64, (size_t)S * nu); A_(d.ub64, (size_t)S * nu);
   A_(d.slot_prob, S); A_(d.age, S); A_(d.next_prob, 1);
   // workgroups of the large-set kernel in flight (each with its tile slab in HBM / L2): four per CU for bulk batches --
@@ -1506,6 +1510,8 @@ int nnmpc_qp_destroy(nnmpc_qp* h) {
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->ev_join3) hipEventDestroy(h->ev_join3);
   if (h->ev_join4) hipEventDestroy(h->ev_join4);
+  if (h->pin_cnt) hipHostFree(h->pin_cnt);
+  if (h->pin_st) hipHostFree(h->pin_st);
   if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->stream3) hipStreamDestroy(h->stream3);
   if (h->stream4) hipStreamDestroy(h->stream4);

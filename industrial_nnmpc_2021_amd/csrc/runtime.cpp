@@ -33,7 +33,13 @@ int nnmpc_device_count(void) {
   return n;
 }
 int nnmpc_set_device(int32_t dev) { HIPCHK(hipSetDevice(dev)); return NNMPC_OK; }
-int nnmpc_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return NNMPC_OK; }
+int nnmpc_device_synchronize(void) {
+  // polling first (the legacy default stream is done when every blocking stream is): a blocking wait can take milliseconds to
+  // wake the caller on some hosts (common.h)
+  for (int i = 0; i < 200000 && hipStreamQuery(0) == hipErrorNotReady; ++i) {}
+  HIPCHK(hipDeviceSynchronize());
+  return NNMPC_OK;
+}
 int nnmpc_dev_mem_info(uint64_t* free_bytes, uint64_t* total_bytes) {
   size_t f = 0, t = 0;
   HIPCHK(hipMemGetInfo(&f, &t));
@@ -210,7 +216,7 @@ int nnmpc_comm_gather_rows(nnmpc_comm* c, const double* send, const int64_t* row
     return NNMPC_EHIP;
   }
   RCCLCHK(g_rccl.GroupEnd());
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(stream_sync(c->stream));
   return NNMPC_OK;
 }
 
@@ -221,7 +227,7 @@ int nnmpc_comm_allreduce_max(nnmpc_comm* c, double* value) {
   HIPCHK(hipMemcpyAsync(c->scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
   RCCLCHK(g_rccl.AllReduce(c->scratch, c->scratch + 1, 1, RCCL_FLOAT64, RCCL_MAX, c->comm, c->stream));
   HIPCHK(hipMemcpyAsync(value, c->scratch + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(stream_sync(c->stream));
   return NNMPC_OK;
 }
 
