@@ -484,6 +484,21 @@ def bench_qp(ctx, workload, B, steps, warmup, sx, method="auto", slots=0, seed0=
                 "traffic_note": "`traffic` = HBM bytes per launch averaged over the group's launches of one step, `traffic_per_step` their sum "
                                 "(PMC passes of scripts/pmc_hbm.sh); algorithmic_bytes_per_step = x0, bounds in + u* out"}
         cands = lambda_rooflines(st, traffic) + [gemm]
+        if st["asm_small_passes"]:
+            # small problems (n <= 724): the whole iteration runs in asm_small_k, one wave per problem (qp_small.h) -- a chain of L2 round
+            # trips (gather of H_AA, rows of Pinv for x), not a throughput kernel: priced against the fp64 peak for the record
+            sach = st["asm_lambda_flops"] / (st["asm_lambda_ms"] * 1e-3) / 1e12 if st["asm_lambda_ms"] > 0 else 0.0
+            tr_s, tr_s_step, tr_s_l = _traffic_of(traffic, ["asm_small_k<2, 3, 4>", "asm_small_k<7, 1, 8>"])
+            cands.append({"kernel": "asm_small_k<2, 3, 4> + asm_small_k<7, 1, 8>: the whole active-set iteration of a problem in one wave (ordered "
+                                    "set, |A| x |A| Cholesky in the MFMA accumulators, x = x_unc - lam Pinv[A, :] from L2, tests, exchange rule, "
+                                    "certificate), sets of up to 32 / 112 bounds", "dtype": "f64", "bound": "mfma", "achieved": sach,
+                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": sach / FP64_PEAK_TFLOPS, "traffic": tr_s, "traffic_per_step": tr_s_step,
+                          "launches": 2 * int(st["asm_small_passes"]), "avg_launch_ms": st["asm_lambda_ms"] / max(1, 2 * st["asm_small_passes"]),
+                          "time_share": st["asm_lambda_ms"] / st["total_ms"],
+                          "algorithmic_flops": "m^3/3 + 2 m^2 per problem and iteration (m = size of its active set); the products with the rows "
+                                               "of Pinv (2 m x window columns) are not counted",
+                          "note": "latency-bound by construction: every iteration is gather -> factorisation -> rows of Pinv -> tests in ONE wave; "
+                                  "the launch lasts as long as its slowest problem (26 iterations at most in this batch, 5.6 on average)"})
         cands.sort(key=lambda r: -r["time_share"])
         res["roofline"], res["roofline_secondary"], res["roofline_third"] = cands[0], cands[1], cands[2]
         res["roofline"]["traffic_unit"] = "HBM bytes per launch; " + tnote
