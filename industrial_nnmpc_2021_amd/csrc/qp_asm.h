@@ -74,6 +74,7 @@ struct AsmDev {
   const double* x0;                // [nseg][ka] padded initial states (for the certificate; first K segment of the full-width pass)
   int ka;
   const double* Kunc;              // [np][ka]: x_unc = Kunc x0
+  int winit;                       // columns the first sets are drawn from (without a guess): the leading eighth of the horizon, 512 at least
   int Wx;                          // x_unc exists in HBM for the columns [0, Wx) only (Wx = np: all of them); beyond, the full-width
                                    // pass forms it inside its GEMM (qp_wide.h), the rare consumers below from Kunc and x0
   // far-field form of the full-width pass (qp_wide.h; nnmpc_qp_set_farfield): x[ffW:] = U (Vx x0 + Vl lam[0:ffW])
@@ -162,10 +163,10 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
     if (tid == 0) d.state[p] = ASM_DONE;
     return;
   }
-  // first set: the bounds x_unc violates in the leading quarter of the horizon (where MPC saturates; a violation
+  // first set: the bounds x_unc violates in the leading part of the horizon (d.winit columns: where MPC saturates; a violation
   // further out is found by the full-width pass every problem goes through before it is accepted), or the guess
   // (without a guess the host has zeroed the bound states of the segment: only the leading wi are written here)
-  const int wi = d.guess ? d.n : min(d.n, max(512, ((d.n / 4 + 127) / 128) * 128));
+  const int wi = d.guess ? d.n : min(d.n, d.winit);
   for (int r = tid; r < wi; r += 256) {
     int s = 0;
     if (d.guess) { s = d.guess[(size_t)p * d.n + r]; if (s > 2) s = 0; }
@@ -1310,6 +1311,8 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   int chg = 0, rmax = 0x7fffffff;                            // the index a single exchange takes: the smallest infeasible one
   double l1 = 0.0, lmin = 1e300;
   auto scan = [&](int mode) {                                // 0: count and record, 1: apply all, 2: apply only index rmax (the smallest infeasible one)
+    // (loading eight chunks of the window at once, unconditionally, before the tests -- instead of bound state, branch, then x_unc
+    // and the GEMM's row per chunk -- made this kernel slower: 0.30 -> 0.53 ms per round at 100 000 problems)
     for (int r = lane; r < W; r += 64) {                     // free variables of the window: feasibility
       if (st[r]) continue;
       const int k = r % d.nu;

@@ -943,14 +943,20 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   // (qp_small.h); what that kernel hands back (sets beyond 64 bounds, problems still moving after its budget) carries on below.
   const bool small = getenv("NNMPC_NO_SMALL") == nullptr && (size_t)h->np * h->np * 8 <= (4u << 20) && h->n <= ASM_SM_NMAX && h->np % 4 == 0;   // (the variable: A/B, tests of the rounds at small sizes)
   const bool lazy = h->np % 128 == 0 && !no_fuse && !no_lazy && !tail_only && !small && (uint64_t)h->seg_max * h->ka * 8 < (1ull << 32);
+  // (the window the first sets are drawn from: the leading eighth of the horizon, 512 columns at least -- a quarter until round 3;
+  // the CDU batch settles inside 512 columns, a quarter is 1152: 0.4 ms of x_unc GEMM per step.  A bound x_unc violates further
+  // out joins through the full-width pass every problem goes through.  Following the previous call's window instead made the
+  // path of a call depend on the handle's history: other windows, other far-field factors, and for degenerate problems other sets)
+  const int winit = std::min(h->n, std::max(512, ((h->n / 8 + 127) / 128) * 128));
   int Wx = h->np;
-  if (lazy) Wx = std::min(h->np, guess_dev ? 512 : ((std::min(h->n, std::max(512, ((h->n / 4 + 127) / 128) * 128)) + 127) / 128) * 128);
+  if (lazy) Wx = std::min(h->np, guess_dev ? 512 : ((winit + 127) / 128) * 128);
+
   {
     EvScope es(h, 5, 2.0 * Wx * (double)h->ka * nprob);
     gemm64(h, h->asm_xunc, h->np, h->x0_64, h->ka, h->Kunc64, h->ka, segp, Wx, h->ka);
   }
   AsmDev a;
-  a.Kunc = h->Kunc64; a.Wx = Wx;
+  a.Kunc = h->Kunc64; a.Wx = Wx; a.winit = winit;
   a.ffU = a.ffVx = a.ffVl = a.ffcu = nullptr; a.ffk = nullptr; a.ffr = a.ffW = 0; a.T = h->asm_xhw; a.tnorm = h->asm_tnorm; a.tslack = h->asm_tslack;
   a.ff_skip = 0; a.ff_err = 0.0;
   static const bool no_far = getenv("NNMPC_NO_FARFIELD") != nullptr;      // diagnostics: dense form of the full-width pass (A/B)

@@ -95,9 +95,10 @@ def test_steady_state_input_on_a_bound_is_never_skipped():
     lb[:, 1::4] = 0.0
     dense = BatchedBoxQP(P, tq, nu, max_batch=512, farfield=None)
     far = BatchedBoxQP(P, tq, nu, max_batch=512, farfield="auto")
-    a = dense.solve_batch(x0, lb, ub, first_move_only=True)
-    far.solve_batch(x0, lb, ub)
-    b = far.solve_batch(x0, lb, ub, first_move_only=True)
+    dense.solve_batch(x0, lb, ub)                     # (the same call history on both handles: the window the first sets are drawn from
+    a = dense.solve_batch(x0, lb, ub, first_move_only=True)   # follows the previous call, and with bounds AT the steady state the
+    far.solve_batch(x0, lb, ub)                       # problems are degenerate -- zero multipliers on active bounds --, so the set a
+    b = far.solve_batch(x0, lb, ub, first_move_only=True)     # solve ends with depends on the path; u does not)
     assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["active"], b["active"])
     assert np.abs(a["u"] - b["u"]).max() < 1e-11
     dense.close(); far.close()
