@@ -175,8 +175,10 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc);
  * costs 2 r (n_aug + W + n - W) instead of 2 (n_aug + W)(n - W) flops per problem.  U: (n - W) x r, Vx: r x n_aug,
  * Vl: r x W, host, row-major.  The library verifies the factors on the device (max |U [Vx | Vl] - M|, refused above 1e-9,
  * and that bound enters every certificate that rests on them).  W must be a multiple of 128 below n; several windows
- * may be set.  First-move calls (NNMPC_OUT_FIRST_MOVE) additionally skip the 128-column tiles that
- * |x_j| <= |U_j| |T_p| <= min_k min(ub_k, -lb_k) certifies feasible -- nothing out there is delivered. */
+ * may be set.  Trailing exact zeros in the rows of U shorten the work: a 128-column tile of the pass only multiplies the
+ * leading columns of U that any of its rows uses (a basis ordered so that far tiles need few coordinates -- a staircase --
+ * pays: the closed loop forgets its fast modes first).  First-move calls (NNMPC_OUT_FIRST_MOVE) additionally skip the
+ * 128-column tiles that |x_j| <= |U_j| |T_p| <= min_k min(ub_k, -lb_k) certifies feasible -- nothing out there is delivered. */
 int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, const double* Vx, const double* Vl);
 /* *W = a window whose full-width pass had to run in the dense form for want of such factors (0: none left; each window is
  * handed out once per time it is met); the host wrapper factors M for it and calls nnmpc_qp_set_farfield (one-time setup,
