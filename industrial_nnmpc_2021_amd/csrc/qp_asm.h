@@ -155,25 +155,30 @@ struct AsmDev {
 
 __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }
 
-// x_unc -> first active-set estimate.
-__global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
-  const int p = blockIdx.x, tid = threadIdx.x;
+// x_unc -> first active-set estimate.  One WAVE per problem, four per workgroup (a workgroup of 256 threads per problem was
+// launch-bound: 100 000 workgroups for 5 KB each).
+__global__ __launch_bounds__(256) void asm_init_k(AsmDev d, int nrows) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= nrows) return;
   const size_t o = (size_t)p * d.np;
   if (p >= d.nseg) {                 // padding rows of the GEMM operands: never active
-    if (tid == 0) d.state[p] = ASM_DONE;
+    if (lane == 0) d.state[p] = ASM_DONE;
     return;
   }
   // first set: the bounds x_unc violates in the leading part of the horizon (d.winit columns: where MPC saturates; a violation
   // further out is found by the full-width pass every problem goes through before it is accepted), or the guess
   // (without a guess the host has zeroed the bound states of the segment: only the leading wi are written here)
   const int wi = d.guess ? d.n : min(d.n, d.winit);
-  for (int r = tid; r < wi; r += 256) {
+  const bool kfix = 64 % d.nu == 0;                          // k = r % nu is then the same for every chunk of 64 columns
+  const double lbf = d.lb[(size_t)p * d.nu + lane % d.nu], ubf = d.ub[(size_t)p * d.nu + lane % d.nu];
+  for (int r = lane; r < wi; r += 64) {
     int s = 0;
     if (d.guess) { s = d.guess[(size_t)p * d.n + r]; if (s > 2) s = 0; }
     else {
-      const int k = r % d.nu;
       const double x = d.xunc[o + r];
-      const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
+      double lb = lbf, ub = ubf;
+      if (!kfix) { const int k = r % d.nu; lb = d.lb[(size_t)p * d.nu + k]; ub = d.ub[(size_t)p * d.nu + k]; }
       s = x > ub ? 1 : (x < lb ? 2 : 0);
     }
     d.st[(size_t)p * d.n + r] = (unsigned char)s;
@@ -181,11 +186,11 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d) {
   // inputs the tests below cannot reason about (every comparison with a NaN is false, so a NaN would pass for
   // "feasible"): NaN / Inf in x0, a NaN bound, lb > ub.  Such a problem is not solved at all.
   int invalid = 0;
-  for (int k = tid; k < d.nu; k += 256) invalid |= !(d.lb[(size_t)p * d.nu + k] <= d.ub[(size_t)p * d.nu + k]);
-  for (int k = tid; k < d.ka; k += 256) invalid |= !(fabs(d.x0[(size_t)p * d.ka + k]) <= 1.79e308);
-  invalid = __syncthreads_or(invalid);
+  for (int k = lane; k < d.nu; k += 64) invalid |= !(d.lb[(size_t)p * d.nu + k] <= d.ub[(size_t)p * d.nu + k]);
+  for (int k = lane; k < d.ka; k += 64) invalid |= !(fabs(d.x0[(size_t)p * d.ka + k]) <= 1.79e308);
+  invalid = __any(invalid);
   // an empty set runs one round like the others: x = x_unc is checked and certified by asm_update_k / asm_wide_k
-  if (tid == 0) {
+  if (lane == 0) {
     d.rounds[p] = 0; d.state[p] = invalid ? ASM_INVALID : ASM_RUN;
     d.prec[p] = (d.use_f32 && !d.guess) ? 0 : 1;       // a caller's guess is expected to be right: confirm it in fp64 at once
     d.redo[p] = 0;
@@ -1407,15 +1412,15 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
 // Full-width check of the problems that settled inside the window (xhw = lamw * H over all columns):
 // a bound violated beyond the window joins the set and the problem runs on; otherwise it is finished
 // exactly like in asm_update_k.  Runs at the start of a round, before asm_count_k.
+// One WAVE per row of LAM (four per workgroup; 256 threads and three barriers per problem were launch and barrier latency:
+// 0.44 ms for the 83 000 problems of the round most sets settle in).
 __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
   // fused_c0 >= 0: the columns [fused_c0, n) were checked and written by asm_wide_gemm_k (qp_wide.h), which raised
   // wflag[p] for a violated bound; this kernel does the columns inside the window, the multiplier statistics and the
   // decision.  fused_c0 < 0: everything from the XHW rows of a plain GEMM (shapes the fused kernel's tiles do not fit).
-  extern __shared__ double wl_lam[];                         // [max_active] multipliers (rare path: x again, from Pinv)
-  __shared__ int cnt[4];
-  __shared__ double red[12];
-  const int tid = threadIdx.x;
-  const int w = blockIdx.x;                                  // row of LAM / XH (and XHW) of the round the problem settled in
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);         // row of LAM / XH (and XHW) of the round the problem settled in
+  if (w >= d.wrows) return;
   const int p = d.rowprob[w];
   if (p < 0) return;
   const size_t o = (size_t)p * d.np, orow = (size_t)w * d.np;
@@ -1430,14 +1435,11 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
   const int* idx = d.idxg + (size_t)p * d.max_active;
   int chg = 0;
   double l1 = 0.0, lmin = 1e300;
-  for (int i = tid; i < m; i += 256) {                       // multipliers of the settled set; the LAMW row goes back to zero
-    const int a = idx[i];
-    const double l = d.lam[orow + a];
-    d.lam[orow + a] = 0.0;
-    wl_lam[i] = l;
+  for (int i = lane; i < m; i += 64) {                       // multipliers of the settled set (the row goes back to zero below)
+    const double l = d.lam[orow + idx[i]];
     l1 += fabs(l); lmin = fmin(lmin, fabs(l));
   }
-  for (int r = tid; r < rend; r += 256) {
+  for (int r = lane; r < rend; r += 64) {
     const int k = r % d.nu;
     const double lb = d.lb[(size_t)p * d.nu + k], ub = d.ub[(size_t)p * d.nu + k];
     const int s = st[r];
@@ -1449,28 +1451,21 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
     } else x = s == 1 ? ub : lb;
     if (r < d.nout) d.u_out[(size_t)p * d.ldu + r] = x;      // final if nothing changes
   }
-  if (fused && tid == 0) { chg += d.wflag[p]; d.wflag[p] = 0; }
+  if (fused && lane == 0) { chg += d.wflag[p]; d.wflag[p] = 0; }
   double x1 = 0.0;
-  for (int k = tid; k < d.ka; k += 256) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
+  for (int k = lane; k < d.ka; k += 64) x1 += fabs(d.x0[(size_t)p * d.ka + k]);
   for (int off = 32; off > 0; off >>= 1) {
     chg += __shfl_xor(chg, off);
     l1 += __shfl_xor(l1, off); x1 += __shfl_xor(x1, off);
     lmin = fmin(lmin, __shfl_xor(lmin, off));
   }
-  if ((tid & 63) == 0) {
-    const int wv = tid >> 6;
-    cnt[wv] = chg; red[wv] = l1; red[4 + wv] = x1; red[8 + wv] = lmin;
-  }
-  __syncthreads();
-  const int tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-  const double L1 = red[0] + red[1] + red[2] + red[3], X1 = red[4] + red[5] + red[6] + red[7];
-  const double LM = fmin(fmin(red[8], red[9]), fmin(red[10], red[11]));
-  const double QI = d.tqmax * X1;                            // >= |q|_inf
+  const int tot = chg;
+  const double QI = d.tqmax * x1;                            // >= |q|_inf
   // (far-field pass: x beyond the window is off by at most max|U V' - M| (|x0|_1 + |lam|_1), its gradient by |P|_inf times that)
-  const double bnd = 2.0 * (d.e1max * X1 + d.e2max * L1) + 1e-14 * (QI + L1) + d.ff_err * (X1 + L1);
-  const bool sure = bnd <= d.stat_tol * d.pscale && LM > bnd;
+  const double bnd = 2.0 * (d.e1max * x1 + d.e2max * l1) + 1e-14 * (QI + l1) + d.ff_err * (x1 + l1);
+  const bool sure = bnd <= d.stat_tol * d.pscale && lmin > bnd;
   if (tot == 0 && !sure) {                                   // P itself has to confirm this one: x as a GEMM row
-    for (int r = tid; r < d.n; r += 256) {                   // (nothing changed: st still is the set x belongs to)
+    for (int r = lane; r < d.n; r += 64) {                   // (nothing changed: st still is the set x belongs to)
       const int k = r % d.nu, s = st[r];
       double x;
       if (s != 0) x = s == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k];
@@ -1479,19 +1474,20 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
       else {                                                 // rare: the product again, straight from Pinv (as asm_tail_k does)
         const double* Hc = d.H + r;
         double a0 = 0.0;
-        for (int i = 0; i < m; ++i) a0 += Hc[(size_t)idx[i] * d.np] * wl_lam[i];
+        for (int i = 0; i < m; ++i) { const int a = idx[i]; a0 += Hc[(size_t)a * d.np] * d.lam[orow + a]; }
         double xu;
         if (r < d.Wx) xu = d.xunc[o + r];
         else {                                               // x_unc beyond the columns kept in HBM: Kunc[r] . x0
           xu = 0.0;
-          for (int k = 0; k < d.ka; ++k) xu += d.Kunc[(size_t)r * d.ka + k] * d.x0[(size_t)p * d.ka + k];
+          for (int k2 = 0; k2 < d.ka; ++k2) xu += d.Kunc[(size_t)r * d.ka + k2] * d.x0[(size_t)p * d.ka + k2];
         }
         x = xu - a0;
       }
       d.x[o + r] = x;
     }
   }
-  if (tid == 0) {
+  for (int i = lane; i < m; i += 64) d.lam[orow + idx[i]] = 0.0;   // the row of LAM goes back to zero
+  if (lane == 0) {
     d.wmark[p] = 1;
     if (tot == 0) {
       d.state[p] = sure ? ASM_CERT : ASM_DONE;

@@ -978,7 +978,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
   // asm_update_k / asm_wide_k of the same round
   if (!guess_dev) HIPCHK(hipMemsetAsync(h->asm_st, 0, (size_t)nprob * h->n, s));   // bound states: asm_init_k writes the leading window only
-  hipLaunchKernelGGL(asm_init_k, dim3(segp), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(asm_init_k, dim3((segp + 3) / 4), dim3(256), 0, s, a, segp);
   const int lds_big = (a.max_active + ASM_TS) * 8;
   int* cnt = h->pin_cnt;
   memset(cnt, 0, ASM_NCNT * sizeof(int));
@@ -1083,7 +1083,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         wide_cols = h->np - c0;
       }
       EvScope es(h, 6, 0.0);
-      hipLaunchKernelGGL(asm_wide_k, dim3(prev_rows), dim3(256), a.max_active * sizeof(double), s, a, fused_c0);
+      hipLaunchKernelGGL(asm_wide_k, dim3((prev_rows + 3) / 4), dim3(256), 0, s, a, fused_c0);
     }
     a.kref = kprev;
     {
