@@ -801,6 +801,9 @@ def cdu_offline_simulator(tasks, T, seed=1, procs_per_task=1):
                               uprev=np.zeros((Nu, 1)), Q=pl["Q"], R=pl["R"], S=pl["S"], ulb=pl["ulb"], uub=pl["uub"], N=pl["N"],
                               xprior=np.zeros((Nx, 1)), setpoints=sp, disturbances=ds, num_data_gen_task=tasks,
                               num_process_per_task=procs_per_task)
+    # the regulator's GPU handle (P^-1, uploads: ~1 s) belongs to the construction of the controller objects, like the DARE and
+    # the condensing above -- the reference builds its DenseQPRegulator before the simulation loop too (lib/linearMPC.py:339-395)
+    sim.regulator._solver()
     return sim
 
 

@@ -614,51 +614,56 @@ class OfflineSimulator:
             res = simulate_chains(self.x0, self.uprev0, self.A, self.B, self.Bd, self.regulator, self.ulb, self.uub,
                                   sel, sp, ds, allow_uncertified=True)
             dt = time.time() - t0
-            rec = np.concatenate([res[k] for k in self._REC_KEYS] + [res["status"][..., None].astype(float),
-                                                                    np.full(res["status"].shape + (1,), dt)], axis=2)
-            rec = np.ascontiguousarray(rec.reshape(-1, width))
         else:
-            rec = np.empty((0, width))
+            res, dt = None, 0.0
         counts = [(hi - lo) * npp * T for lo, hi in cuts]
         if world == 1:
-            full = rec
-        elif comm is not None:
-            from . import _lib
-            send = _lib.DeviceArray.from_host(rec) if rec.size else None
-            recv = _lib.DeviceArray((sum(counts), width), np.float64) if rank == 0 else None
-            comm.gather_rows(send, counts, width, recv, root=0)        # the single collective of the job
-            full = recv.to_host() if rank == 0 else None
-            for a in (send, recv):
-                if a is not None:
-                    a.free()
-        elif gather is not None:
-            full = gather(rec, counts)
+            # single process: the records are already chain-major (nc, T, width of the key) -- no packing, no copy
+            views = {k: res[k] for k in self._REC_KEYS} if res is not None else {k: np.empty((0, T, 0)) for k in self._REC_KEYS}
+            status = res["status"].astype(np.int32) if res is not None else np.empty((0, T), np.int32)
+            dtimes = np.full(len(tasks) * npp, dt)
         else:
-            raise ValueError("generate_dataset: world > 1 needs comm= (distributed.Comm) or gather=")
-        if rank != 0:
-            return None
-        full = full.reshape(len(tasks) * npp, T, width)
-        status = full[:, :, -2].astype(np.int32)
+            if res is not None:
+                rec = np.concatenate([res[k] for k in self._REC_KEYS] + [res["status"][..., None].astype(float),
+                                                                        np.full(res["status"].shape + (1,), dt)], axis=2)
+                rec = np.ascontiguousarray(rec.reshape(-1, width))
+            else:
+                rec = np.empty((0, width))
+            if comm is not None:
+                from . import _lib
+                send = _lib.DeviceArray.from_host(rec) if rec.size else None
+                recv = _lib.DeviceArray((sum(counts), width), np.float64) if rank == 0 else None
+                comm.gather_rows(send, counts, width, recv, root=0)        # the single collective of the job
+                full = recv.to_host() if rank == 0 else None
+                for a in (send, recv):
+                    if a is not None:
+                        a.free()
+            elif gather is not None:
+                full = gather(rec, counts)
+            else:
+                raise ValueError("generate_dataset: world > 1 needs comm= (distributed.Comm) or gather=")
+            if rank != 0:
+                return None
+            full = full.reshape(len(tasks) * npp, T, width)
+            status = full[:, :, -2].astype(np.int32)
+            dtimes = full[:, 0, -1]
+            splits = np.concatenate(([0], np.cumsum([Nx, Nu, Nx, Nu, Nu])))
+            views = {k: full[:, :, splits[i]:splits[i + 1]] for i, k in enumerate(self._REC_KEYS)}
         if not allow_uncertified and (status != 0).any():
             c, t = np.argwhere(status != 0)[0]
             raise RuntimeError(f"generate_dataset: {int((status != 0).sum())} regulator solve(s) not certified optimal (first: chain "
                                f"{c}, step {t}); pass allow_uncertified=True to keep the data anyway")
-        splits = np.cumsum([Nx, Nu, Nx, Nu, Nu])
-        data = {k: [] for k in self._REC_KEYS + ("status",)}
-        times = []
-        for i, task in enumerate(tasks):
-            for proc in range(npp):
-                row = full[i * npp + proc]
-                parts = np.split(row[:, :splits[-1]], splits[:-1], axis=1)
-                one = {k: np.ascontiguousarray(v) for k, v in zip(self._REC_KEYS, parts)}
-                one["status"] = status[i * npp + proc]
-                one["data_gen_time"] = float(row[0, -1])
-                if write_files:
+        if write_files:
+            for i, task in enumerate(tasks):
+                for proc in range(npp):
+                    j = i * npp + proc
+                    one = {k: np.ascontiguousarray(views[k][j]) for k in self._REC_KEYS}
+                    one["status"] = status[j]
+                    one["data_gen_time"] = float(dtimes[j])
                     _save_training_data(one, str(task) + '-' + str(proc) + '-' + data_filename)
-                for k in data:
-                    data[k].append(one[k])
-                times.append(one["data_gen_time"])
-        out = {k: np.concatenate(v, axis=0) for k, v in data.items()}
-        out["data_gen_time"] = float(np.mean(times)) if times else 0.0
+        out = {k: np.ascontiguousarray(views[k]).reshape(len(tasks) * npp * T, -1) for k in self._REC_KEYS}
+        out["status"] = status.reshape(-1)
+        out["data_gen_time"] = float(np.mean(dtimes)) if len(dtimes) else 0.0
         return out
+
 
