@@ -39,5 +39,19 @@ for n, (calls, v) in sorted(fe.items(), key=lambda kv: -kv[1][1]):
     fb = v * 2 * 1024; wb = wr.get(n, [0, 0.0])[1] * 1024; ms = tf.get(n, 0.0)
     res["kernels"][n] = {"launches": calls, "fetch_bytes_corrected": fb, "write_bytes": wb, "time_ms_under_pmc": ms,
                          "hbm_bytes_per_launch": (fb + wb) / max(1, calls), "hbm_TBps": (fb + wb) / (ms * 1e-3) / 1e12 if ms else None}
+def steady_state(res):
+    """HBM bytes of a step once the far-field factors are there: one of the profiled passes is the handle's setup pass (dense form
+    of the full-width pass: asm_wide_gemm_k<1>, far_verify_k), the far-field kernels ran in the others only."""
+    sp = res["steps_profiled"]
+    setup_only = ("asm_wide_gemm_k<1>", "far_verify_k", "gemm_nt_f64_k")
+    far_only = ("asm_wide_gemm_k<2>", "asm_wide_t_k", "asm_wide_tnorm_k")
+    tot = 0.0
+    for n, k in res["kernels"].items():
+        b = k["fetch_bytes_corrected"] + k["write_bytes"]
+        if any(t in n for t in setup_only): continue
+        tot += b / (sp - 1) if any(t in n for t in far_only) else b / sp
+    return tot
+if any("asm_wide_gemm_k<1>" in n for n in res["kernels"]) and res["steps_profiled"] > 1:
+    res["steady_state_bytes_per_step"] = steady_state(res)
 json.dump(res, open(out, "w"), indent=1)
 for n, k in res["kernels"].items(): print(n, k["launches"], f"{k['hbm_bytes_per_launch'] / 1e6:.1f} MB/launch", k["hbm_TBps"])
