@@ -11,16 +11,22 @@
 //                                            inside the column window (past the last active bound) while the set still moves,
 //                                            all columns once when it settles
 //     fp64 feasibility / multiplier-sign tests, the exchange rule of asm_update_k (all infeasible indices change sides while their
-//     number keeps falling, ASM_GRACE iterations of grace, then Murty's least-index single exchanges), the certificate of
+//     number keeps falling, ASM_SM_GRACE iterations of grace, then Murty's least-index single exchanges), the certificate of
 //     asm_update_k (inverse-error bound, else ASM_DONE: asm_certify_k checks with P itself).
 // Two instances, launched one after the other over all problems of the segment (a wave whose problem is not running exits at once):
-//     asm_small_k<2, 3, 4>   sets of up to 32 bounds -- the common case (CSTRs batch: 17 on average) -- in at most 128 VGPRs: four
-//                         waves per SIMD hide the L2 round trips of the gathers (the iteration is a chain of them)
-//     asm_small_k<7, 1, 8>   sets of up to 112 bounds (28 accumulator tiles): the few problems the first instance handed back
+//     asm_small_k<2, 3, 4>   sets of up to 32 bounds -- the common case (CSTRs batch: 17 on average) -- in 146 VGPRs: three waves per
+//                            SIMD hide the L2 round trips of the gathers (the iteration is a chain of them)
+//     asm_small_k<7, 1, 8>   sets of up to 112 bounds: the problems the first instance handed back (one in twenty of that batch); a
+//                            four-block solve up to 64 bounds, a seven-block one (first five block columns' tiles in LDS, identity
+//                            padding for any size) beyond
 // A problem whose set outgrows an instance, or that is still moving after `budget` iterations, is handed back as it stands
 // (bound states, exchange-rule memory, iteration count): it stays ASM_RUN and the next instance, then the lock-step rounds / the
 // device tail carry on.  Same arithmetic (fp64 everywhere), same tests, same certificate: the answers are the ones the rounds give.
-// One wave per workgroup: a problem that needs 40 iterations does not hold the LDS of three finished neighbours.
+// One wave per workgroup: a problem that needs 26 iterations does not hold the LDS of three finished neighbours.
+// What did not pay (CSTRs-size 10 000 problems, ms per step): a third instance for 33 .. 64 bounds in between (0.32 + 0.52 + 0.69
+// against 0.32 + 0.70: the slowest problem sets the time of each launch and passes through all of them); starting the problems
+// whose FIRST set has more than 32 bounds in the large instance at once, on a second stream beside the small one (1.8 against
+// 1.4: the slowest problem starts small); seven solve instances in one kernel (60 .. 230 registers spilled to scratch).
 #pragma once
 #include "qp_asm.h"
 
