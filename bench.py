@@ -25,7 +25,33 @@ import subprocess
 import sys
 import time
 
-import numpy as np
+
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask and cgroup quota (a GPU box hands a container 16 of 256)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# BLAS pools sized well below the CPUs the process may use, BEFORE numpy loads its OpenBLAS (whose default is one thread per logical
+# CPU of the HOST: 2 x 128 threads on a 256-thread box inside a 16-CPU container).  After any BLAS call the pool's threads spin for
+# a while; more spinning threads than the cgroup's quota and the whole process is throttled for the rest of the scheduler period --
+# the thread that polls the GPU included.  Measured on the CSTRs-size leg (1.4 ms per step): with the default pools 12 of 28 solver
+# handles saw ~16 ms added to EVERY call (outside the library's own clock around the call); with 16 threads a CDU-size call now
+# and then took 63 instead of 11 ms right after a host SVD; with 8 threads, 0 of 28 and none.  (threadpoolctl limits set after the
+# pools exist do not help: 12 of 42.)  An explicit setting in the environment wins.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(max(1, min(8, usable_cpus() // 2))))
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -291,7 +317,7 @@ def cpu_baseline(P, tq, nu, N, x0, lb, ub, budget_s, workload, full):
     res = {"value": done / dt, "unit": "solves/s", "cores": int(threads), "kind": "port",
            "sample": f"{done} problem(s) of the same seeded batch, n={n}, m={2 * n}, dense G, cvxopt-default tolerances, "
                      f"mean {np.mean(its):.1f} PDIP iterations, {dt:.1f} s, one process with {threads} BLAS threads",
-           "cpu_model": model, "blas": blas, "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(),
+           "cpu_model": model, "blas": blas, "usable_cpus": usable_cpus(), "host_logical_cpus": os.cpu_count(), "host_physical_cores": physical_cores(),
            "blas_threads_used": int(threads),
            "paper_reference": ("CVXOPT 35 s/solve mean, 47 s worst on a 2.4 GHz cluster CPU (KumarRawlingsWright2021 p.9) = 0.029 solves/s"
                                if workload == "cdu" else
@@ -1048,9 +1074,8 @@ def main():
             out["chains_task"] = timed("chains_task", chains_task_leg, ctx, 149, 2400)
             cfg = {}
             t_cfg = time.perf_counter()
-            # (three handles, the fastest is reported, all three are listed: on this pool a handle created after others have come and
-            # gone sometimes sees ~16.7 ms added to every profiled call -- outside the library's own clock around the call, which
-            # reads 1.4 ms either way -- and a 1.4 ms step cannot hide that the way a 21 ms one does)
+            # (three handles, the fastest is reported, all three are listed: a 1.4 ms step shows every host-side stall -- see the
+            # note on the BLAS pools at the top of this file, the one cause found so far)
             runs, r2, h2 = [], None, None
             for _ in range(3):
                 rr, hh = bench_qp(ctx, "cstrs", 10000, max(args.steps, 5), 2, args.sx, want_buffers=True)
