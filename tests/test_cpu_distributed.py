@@ -219,3 +219,17 @@ def test_chain_tasks_are_sharded_over_ranks_and_gathered_in_task_order():
             p.join(120)
             assert p.exitcode == 0
         assert out.get(timeout=5) is True
+
+
+def test_bench_sizes_the_blas_pools_below_the_cpu_quota():
+    """bench.py, before it imports numpy: OPENBLAS / OMP / MKL thread counts default to min(8, usable CPUs / 2) -- OpenBLAS's own
+    default (one thread per logical CPU of the host) overruns a container's CPU quota and gets the GPU-polling thread throttled
+    (DESIGN.md section 5); an explicit setting in the environment is left alone."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('OPENBLAS_NUM_THREADS', None); os.environ['OMP_NUM_THREADS'] = '3'; "
+            "import bench; n = bench.usable_cpus(); assert n >= 1; "
+            "assert os.environ['OPENBLAS_NUM_THREADS'] == str(max(1, min(8, n // 2))), os.environ['OPENBLAS_NUM_THREADS']; "
+            "assert os.environ['OMP_NUM_THREADS'] == '3'; print('ok')") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
