@@ -798,7 +798,11 @@ void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, con
             size_t ldb, int M, int N, int K, const int* rowphase = nullptr, int want = 0,
             const int* kdyn = nullptr, const int* mdyn = nullptr, bool kblocks = false, const int* rowmap = nullptr) {
   // kblocks: kdyn holds one bound per 64 rows of A (else one for the launch); rowmap: gather / scatter of the rows (gemm64.h)
-  if (M % 128 == 0 && N % 128 == 0 && K % G64_KC == 0) {
+  // (fewer 128 x 128 tiles than CUs -- the x_unc product of a chain step: 149 rows -- leave most of the chip idle behind a few
+  // long K loops: four times as many 64 x 64 tiles finish sooner)
+  static const bool small64 = getenv("NNMPC_NO_SMALL_GEMM") == nullptr;   // (the variable: A/B)
+  const bool few = small64 && !rowmap && (M / 128) * (N / 128) < 200;
+  if (M % 128 == 0 && N % 128 == 0 && K % G64_KC == 0 && !few) {
     const int ntm = M / 128, ntn = N / 128;
     hipLaunchKernelGGL(gemm_nt_f64_t128_k, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, h->stream, C, ldc, A, lda, B, ldb, K, ntm, ntn,
                        rowphase, want, kdyn, kblocks ? 2 : 0, mdyn, rowmap);
