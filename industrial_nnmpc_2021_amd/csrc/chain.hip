@@ -438,16 +438,19 @@ int nnmpc_chain_run(nnmpc_chain* c, int32_t T, const double* xs, const double* u
     if (sd) HIPCHK(hipMemcpy(cc, d, sd * 8, hipMemcpyHostToDevice));
     xs_d = a; us_d = b; d_d = cc;
   }
-  HIPCHK(hipEventRecord(c->e0, c->stream));
+  // the step's own kernels go on the regulator handle's stream: pre -> solve -> post in stream order, no host wait in between
+  // (they used to run on the chain's stream behind a host synchronisation per step)
+  hipStream_t qs = nnmpc_qp_stream_internal(c->qp);
+  HIPCHK(stream_sync(c->stream));                            // (a reset's copies)
+  HIPCHK(hipEventRecord(c->e0, qs));
   double solve_s = 0.0;
   const size_t lds = (size_t)(nx + nu + nd) * sizeof(double);
   for (int t = 0; t < T; ++t) {
     const double* xs_t = xs_d + (size_t)t * nc * nx;
     const double* us_t = us_d + (size_t)t * nc * nu;
     const double* d_t = nd ? d_d + (size_t)t * nc * nd : nullptr;
-    hipLaunchKernelGGL(chain_pre_k, dim3(nc), dim3(256), 0, c->stream, nx, nu, c->x, c->uprev, xs_t, us_t, c->ulb, c->uub,
+    hipLaunchKernelGGL(chain_pre_k, dim3(nc), dim3(256), 0, qs, nx, nu, c->x, c->uprev, xs_t, us_t, c->ulb, c->uub,
                        c->qx0, c->lb, c->ub, xr_d + (size_t)t * nc * nx, ur_d + (size_t)t * nc * nu);
-    HIPCHK(stream_sync(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = nnmpc_qp_solve_batch_ex(c->qp, nc, c->qx0, c->lb, c->ub, (warm_start && c->have_guess) ? c->guess : nullptr,
                                            c->first, c->act, c->status, nullptr, NNMPC_DEVICE, NNMPC_OUT_FIRST_MOVE);
@@ -455,16 +458,16 @@ int nnmpc_chain_run(nnmpc_chain* c, int32_t T, const double* xs, const double* u
     if (rc) {
       // the chain state is half advanced (x, uprev of step t recorded, not stepped): drain the stream and drop the warm-start
       // guess so that a later call starts from a consistent state (the caller should nnmpc_chain_reset)
-      hipStreamSynchronize(c->stream);
+      hipStreamSynchronize(qs);
       c->have_guess = false;
       return rc;
     }
-    hipLaunchKernelGGL(chain_post_k, dim3(nc), dim3(256), lds, c->stream, nx, nu, nd, c->n, c->words, c->Mt, c->x, c->uprev,
+    hipLaunchKernelGGL(chain_post_k, dim3(nc), dim3(256), lds, qs, nx, nu, nd, c->n, c->words, c->Mt, c->x, c->uprev,
                        us_t, d_t, c->first, c->act, c->status, uu_d + (size_t)t * nc * nu, st_d + (size_t)t * nc, c->guess);
     c->have_guess = true;
   }
-  HIPCHK(hipEventRecord(c->e1, c->stream));
-  HIPCHK(stream_sync(c->stream));
+  HIPCHK(hipEventRecord(c->e1, qs));
+  HIPCHK(stream_sync(qs));
   HIPCHK(hipGetLastError());
   float ms = 0.f;
   hipEventElapsedTime(&ms, c->e0, c->e1);

@@ -23,3 +23,7 @@ inline hipError_t stream_sync(hipStream_t s) {
   return hipStreamSynchronize(s);
 }
 }  // namespace nnmpc
+// (library-internal, not part of the C ABI) the stream a regulator handle launches on: nnmpc_chain_run puts its own kernels of a
+// lock-step step on it, so that a step needs no host wait between them and the solve
+struct nnmpc_qp;
+hipStream_t nnmpc_qp_stream_internal(nnmpc_qp* h);

@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d, int nrows) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= nrows) return;
   const size_t o = (size_t)p * d.np;
-  if (p >= d.nseg) {                 // padding rows of the GEMM operands: never active
-    if (lane == 0) d.state[p] = ASM_DONE;
+  if (p >= d.nseg) {                 // padding rows of the GEMM operands: never active (and not ASM_DONE: the check with P itself
+    if (lane == 0) d.state[p] = ASM_CERT;   // selects its rows by that tag -- 107 padding rows of a 149-chain step would cost 0.1 ms)
     return;
   }
   // first set: the bounds x_unc violates in the leading part of the horizon (d.winit columns: where MPC saturates; a violation

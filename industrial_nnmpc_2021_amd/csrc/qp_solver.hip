@@ -1027,6 +1027,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
 #endif
     }
   }
+  static const bool trace_tail = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations per problem
+  const bool defer_cnt = tail_only && !trace_tail;
   if (tail_only) {
     // A call of at most 256 problems -- the lock-step chains of a task, a controller's single QP -- is finished on the
     // device from the start (asm_tail_k: count -> fp64 solve -> x over all columns -> exchange rule, one workgroup per
@@ -1035,11 +1037,14 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
     const int lds_tail = (a.max_active + ASM_TS + ASM_TAIL_AREA) * 8 + ((h->n + 15) / 16) * 16 + ASM_TAIL_EXTRA;
     hipLaunchKernelGGL(asm_tail_k, dim3(nprob), dim3(256), lds_tail, s, a, h->asm_tail_budget);
-    HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(stream_sync(s));
+    // (the counters are read together with the status at the end of the segment -- one host round trip per call instead of two:
+    // a chain step is such a call, 0.45 ms of which ~0.04 ms was this wait; the check with P is launched unconditionally then)
+    if (!defer_cnt) {
+      HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(stream_sync(s));
+    }
     h->stats.asm_rounds += 1;
-    static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations per problem
-    if (trace) {
+    if (trace_tail) {
       std::vector<int> rd(nprob), mg(nprob);
       hipMemcpy(rd.data(), h->asm_rounds, nprob * sizeof(int), hipMemcpyDeviceToHost);
       hipMemcpy(mg.data(), h->asm_mg, nprob * sizeof(int), hipMemcpyDeviceToHost);
@@ -1253,15 +1258,17 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(stream_sync(s));
   }
-  h->stats.asm_full_checks += cnt[ASM_CNT_DONE];
-  if (cnt[ASM_CNT_DONE] > 0) {
+  if (!defer_cnt) h->stats.asm_full_checks += cnt[ASM_CNT_DONE];
+  if (defer_cnt || cnt[ASM_CNT_DONE] > 0) {                // (row blocks without an ASM_DONE row leave these GEMMs at once)
     gemm64(h, h->q64_all, h->np, h->x0_64, h->ka, h->tq64, h->ka, segp, h->np, h->ka, h->asm_state, ASM_DONE);
     gemm64(h, h->asm_xh, h->np, h->asm_x, h->np, h->P64, h->np, segp, h->np, h->np, h->asm_state, ASM_DONE);
   }
   hipLaunchKernelGGL(asm_certify_k, dim3(nprob), dim3(256), 0, s, a, h->pscale);
   int* st = h->pin_st;
   HIPCHK(hipMemcpyAsync(st, h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (defer_cnt) HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(stream_sync(s));
+  if (defer_cnt) h->stats.asm_full_checks += cnt[ASM_CNT_DONE];
   HIPCHK(hipGetLastError());
   std::vector<int> fb;
   int ninvalid = 0;
@@ -1314,6 +1321,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
 }
 
 }  // namespace
+
+hipStream_t nnmpc_qp_stream_internal(nnmpc_qp* h) { return h->stream; }
 
 extern "C" {
 
