@@ -1755,30 +1755,58 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
     const int xlim = fast ? d.n : min(d.n, ((lastact + 1 + d.nu + 255) / 256) * 256);
     int xdone = xlim;                                        // columns whose decisions dec[] are this iteration's
     // x over the columns [r0, r1) and the feasibility tests of the free variables there
-    auto xpass = [&](int r0, int r1, int& ninf, int& rmin) {
-    for (int r = r0 + tid; r < r1; r += 256) {
-      const int sr = st[r];
+    // one column: x from the product (free) or the bound (active), test, write-out, decision
+    auto xcol = [&](int r, int sr, double prod, int& ninf, int& rmin) {
       const int k = r % d.nu;
       const double lb = lbp[k], ub = ubp[k];
       unsigned char dc = 255;
       double x;
       if (sr == 0) {
-        // (lam H)[r] = sum_i lam_i H[idx_i][r], the GEMM's indexing: consecutive threads read consecutive columns of
-        // row idx_i (H[r][idx_i] -- the same number, H is symmetric -- would touch one cache line per thread)
+        x = d.xunc[o + r] - prod;
+        if (x > ub + d.bound_tol) dc = 1; else if (x < lb - d.bound_tol) dc = 2;
+      } else x = sr == 1 ? ub : lb;
+      if (r < d.nout) d.u_out[(size_t)p * d.ldu + r] = x;      // final once nothing changes
+      d.x[o + r] = x;                                          // ... and as a GEMM row, should P itself have to confirm it
+      dec[r] = dc;
+      if (dc != 255) { ++ninf; rmin = min(rmin, r); }
+    };
+    auto xpass = [&](int r0, int r1, int& ninf, int& rmin) {
+    // (lam H)[r] = sum_i lam_i H[idx_i][r], the GEMM's indexing: consecutive threads read consecutive columns of row idx_i
+    // (H[r][idx_i] -- the same number, H is symmetric -- would touch one cache line per thread).  A thread owns FOUR consecutive
+    // columns: one 32-byte load per row of Pinv and thread, eight rows in flight (the entries come from L2 / Infinity Cache at
+    // ~1 us each; 8-byte loads, sixteen in flight, made this loop -- (columns / 256) m / 16 dependent round trips -- most of an
+    // iteration with a large set: the columns beyond the window of a 149-chain step took 0.1 of its 0.3 ms)
+    int rs = r0;                                             // the scalar loop below starts here
+    if ((d.np & 3) == 0 && (r0 & 3) == 0) {
+      const int rv1 = r0 + ((r1 - r0) & ~3);
+      for (int r = r0 + 4 * tid; r < rv1; r += 1024) {
+        const int s0 = st[r], s1 = st[r + 1], s2 = st[r + 2], s3 = st[r + 3];
+        f64x4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+        if (s0 == 0 || s1 == 0 || s2 == 0 || s3 == 0) {
+          const double* Hc = d.H + r;
+          int i = 0;
+          for (; i + 8 <= m; i += 8) {
+            f64x4_t h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = *reinterpret_cast<const f64x4_t*>(Hc + (size_t)lst[i + u] * d.np);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 += h[u] * rA[i + u]; a1 += h[u + 1] * rA[i + u + 1]; }
+          }
+          for (; i < m; ++i) a0 += *reinterpret_cast<const f64x4_t*>(Hc + (size_t)lst[i] * d.np) * rA[i];
+          a0 += a1;
+        }
+        xcol(r, s0, a0[0], ninf, rmin); xcol(r + 1, s1, a0[1], ninf, rmin);
+        xcol(r + 2, s2, a0[2], ninf, rmin); xcol(r + 3, s3, a0[3], ninf, rmin);
+      }
+      rs = rv1;
+    }
+    for (int r = rs + tid; r < r1; r += 256) {
+      const int sr = st[r];
+      double prod = 0.0;
+      if (sr == 0) {
         const double* Hc = d.H + r;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int i = 0;
-        // sixteen loads in flight per thread (the entries come from L2 / Infinity Cache at ~1 us each: four at a time made this
-        // loop -- m / 4 dependent round trips per 256 columns -- most of an iteration)
-        for (; i + 16 <= m; i += 16) {
-          double h[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) h[u] = Hc[(size_t)lst[i + u] * d.np];
-#pragma unroll
-          for (int u = 0; u < 16; u += 4) {
-            a0 += h[u] * rA[i + u]; a1 += h[u + 1] * rA[i + u + 1]; a2 += h[u + 2] * rA[i + u + 2]; a3 += h[u + 3] * rA[i + u + 3];
-          }
-        }
         for (; i + 4 <= m; i += 4) {
           a0 += Hc[(size_t)lst[i] * d.np] * rA[i];
           a1 += Hc[(size_t)lst[i + 1] * d.np] * rA[i + 1];
@@ -1786,13 +1814,9 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
           a3 += Hc[(size_t)lst[i + 3] * d.np] * rA[i + 3];
         }
         for (; i < m; ++i) a0 += Hc[(size_t)lst[i] * d.np] * rA[i];
-        x = d.xunc[o + r] - ((a0 + a1) + (a2 + a3));
-        if (x > ub + d.bound_tol) dc = 1; else if (x < lb - d.bound_tol) dc = 2;
-      } else x = sr == 1 ? ub : lb;
-      if (r < d.nout) d.u_out[(size_t)p * d.ldu + r] = x;    // final once nothing changes
-      d.x[o + r] = x;                                        // ... and as a GEMM row, should P itself have to confirm it
-      dec[r] = dc;
-      if (dc != 255) { ++ninf; rmin = min(rmin, r); }
+        prod = (a0 + a1) + (a2 + a3);
+      }
+      xcol(r, sr, prod, ninf, rmin);
     }
     };
     xpass(0, xlim, ninf, rmin);
