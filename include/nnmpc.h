@@ -178,11 +178,15 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc);
  * may be set.  Trailing exact zeros in the rows of U shorten the work: a 128-column tile of the pass only multiplies the
  * leading columns of U that any of its rows uses (a basis ordered so that far tiles need few coordinates -- a staircase --
  * pays: the closed loop forgets its fast modes first).  First-move calls (NNMPC_OUT_FIRST_MOVE) additionally skip the
- * 128-column tiles that |x_j| <= |U_j| |T_p| <= min_k min(ub_k, -lb_k) certifies feasible -- nothing out there is delivered. */
+ * 128-column tiles that |x_j| <= |U_j| |T_p| + e_far (|x0|_1 + |lam|_1) <= min_k min(ub_k, -lb_k) - bound_tol certifies feasible
+ * (e_far = the verified max |U [Vx | Vl] - M|) -- nothing out there is delivered.  Replacing a window's factors releases the old
+ * ones; a refused set leaves nothing behind. */
 int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, const double* Vx, const double* Vl);
 /* *W = a window whose full-width pass had to run in the dense form for want of such factors (0: none left; each window is
  * handed out once per time it is met); the host wrapper factors M for it and calls nnmpc_qp_set_farfield (one-time setup,
- * like the inverse itself). */
+ * like the inverse itself).  The library never factors M itself: a caller that binds the C ABI directly -- or drives
+ * nnmpc_chain_run -- has to poll this after its calls (at most 16 windows are queued), otherwise its full-width passes stay in
+ * the dense form (correct, 2.6 x the flops at the CDU size). */
 int nnmpc_qp_farfield_missing(nnmpc_qp* h, int32_t* W);
 
 /* out (B x nu) = u[:, 0:nu] + us for HBM-resident sequences u (B rows of ldu doubles): the absolute first moves, i.e.

@@ -57,6 +57,7 @@ class DeviceChains:
         _lib.check(self._lib.nnmpc_chain_run(self._h, T, p(Xs), p(Us), p(D) if self.nd else None, p(out["x"]),
                                              p(out["uprev"]), p(out["u"]), p(out["status"]), int(bool(warm_start)),
                                              _lib.HOST), "nnmpc_chain_run")
+        self._after_run()
         return out
 
     def run_device(self, T, Xs, Us, D, x_rec, uprev_rec, u_rec, status, warm_start=True):
@@ -64,6 +65,14 @@ class DeviceChains:
         q = lambda a: None if a is None else C.c_void_p(a.data_ptr())
         _lib.check(self._lib.nnmpc_chain_run(self._h, int(T), q(Xs), q(Us), q(D), q(x_rec), q(uprev_rec), q(u_rec),
                                              q(status), int(bool(warm_start)), _lib.DEVICE), "nnmpc_chain_run")
+        self._after_run()
+
+    def _after_run(self):
+        """More than 256 chains advance in lock-step rounds whose full-width pass wants far-field factors for its window: the
+        library queues the windows it met without (nnmpc_qp_farfield_missing), the regulator's wrapper factors them."""
+        fa = getattr(self._qp, "_farfield_auto", None)
+        if fa is not None:
+            fa()
 
     def last_ms(self):
         """(hipEvent time of the last run, host time spent inside its regulator solves), milliseconds."""

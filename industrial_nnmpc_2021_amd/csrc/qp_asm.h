@@ -88,6 +88,7 @@ struct AsmDev {
   double *tnorm, *tslack;          // [row tiles * 128] |T_p| and min_k min(ub_k, -lb_k) (first-move calls)
   int ff_skip;                     // first-move call: column tiles certified feasible by |U_j| |T_p| are not evaluated
   double ff_err;                   // |P|_inf * max |U V' - M| of the factors the last full-width pass used (0: dense form): enters the certificate
+  double ff_efar;                  // max |U V' - M| itself: x beyond the window is off by at most ff_efar (|x0|_1 + |lam|_1) -- enters the skip test of first-move calls
   const double* H;                 // [np][np] fp64 inverse Hessian
   const float* H32;                // the same rounded to f32 (operand of the f32 GEMM; the f32 rounds gather S from it: same values as
                                    // rounding the fp64 entries on the fly, half the bytes)

@@ -61,6 +61,7 @@ struct QpDev {
   int seg_count, max_rounds;
   int *phase, *f_factor, *f_solve, *istep, *ipm_it, *nfac, *prounds, *rcnt, *psub, *fail, *stale;
   int *pninf, *pgrace;   // polish exchange rule: fewest infeasible indices seen, rounds of grace left (see kkt_check)
+  int* ptie;             // polish tie round done (see kkt_check): bounds violated by less than bound_tol were made active once
   float *mu, *gap, *smu, *qscale;
   double* rz;
   int* counters;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void refill_k(QpDev d) {
     d.phase[p] = warm ? PH_POLISH : PH_INIT;
     d.f_factor[p] = d.f_solve[p] = 0;
     d.ipm_it[p] = d.nfac[p] = d.prounds[p] = d.rcnt[p] = d.psub[p] = d.fail[p] = d.stale[p] = 0;
-    d.pninf[p] = 0x7fffffff; d.pgrace[p] = POLISH_GRACE;
+    d.pninf[p] = 0x7fffffff; d.pgrace[p] = POLISH_GRACE; d.ptie[p] = 0;
     d.mu[p] = d.gap[p] = d.smu[p] = 0.f; d.rz[p] = 0.0;
   }
 }
@@ -335,6 +336,34 @@ __device__ int kkt_check(const QpDev& d, int p, int* shi, double* shd) {
   bad = block_sum_i(bad, shi);
   gfree = block_maxd(gfree, shd);
   const int pr = d.prounds[p] + 1;
+  // Tie rule ("a bound is active iff its multiplier is > 0", as the oracle and the active-set path have it): a free variable that
+  // sits beyond its bound by LESS than bound_tol passes the feasibility test above, but at the exact optimum that bound is active
+  // with a tiny positive multiplier.  Once per problem, when everything else is settled, such bounds are made active and the set is
+  // solved again; a multiplier that then comes out with the wrong sign drops the bound by the ordinary rule, and it is not
+  // re-added (ptie): at most one extra polish round, only for problems that have such a tie.
+  if (bad == 0 && pr <= d.max_polish && !d.ptie[p]) {
+    int ties = 0;
+    for (int r = tid; r < n; r += 256) {
+      if (d.st[o + r] != 0) continue;
+      const int c = r % d.nu;
+      const double x = d.x[o + r];
+      const double lb = d.lb64[(size_t)p * d.nu + c], ub = d.ub64[(size_t)p * d.nu + c];
+      if (x > ub) { d.st[o + r] = 1; d.x[o + r] = ub; ++ties; }
+      else if (x < lb) { d.st[o + r] = 2; d.x[o + r] = lb; ++ties; }
+    }
+    ties = block_sum_i(ties, shi);
+    __syncthreads();
+    if (tid == 0) d.ptie[p] = 1;
+    if (ties > 0) {
+      for (int r = tid; r < n; r += 256) d.v64[o + r] = d.x[o + r];
+      if (tid == 0) {
+        d.stale[p] = ties <= d.stale_max_changes;
+        d.prounds[p] = pr; d.psub[p] = PS_START; d.rcnt[p] = 0;
+        d.f_factor[p] = d.f_solve[p] = 0;
+      }
+      return 0;
+    }
+  }
   if (bad == 0 || pr > d.max_polish) {
     // stationarity of the free block certifies the refinement itself
     const double gs = d.pscale * (double)d.qscale[p];
@@ -700,6 +729,7 @@ struct nnmpc_qp {
   int* pin_cnt = nullptr;            // [ASM_NCNT]
   int* pin_st = nullptr;             // [seg_max]
   bool profiling;
+  bool gemm_error = false;      // a GEMM was asked for in a form no kernel implements (gemm64): the call in progress fails
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used;
   struct EvRec { int kind; size_t e0, e1; double flops; };
@@ -806,6 +836,13 @@ void gemm64(nnmpc_qp* h, double* C, size_t ldc, const double* A, size_t lda, con
     const int ntm = M / 128, ntn = N / 128;
     hipLaunchKernelGGL(gemm_nt_f64_t128_k, dim3(g64_grid(ntm, ntn)), dim3(256), G64_LDS, h->stream, C, ldc, A, lda, B, ldb, K, ntm, ntn,
                        rowphase, want, kdyn, kblocks ? 2 : 0, mdyn, rowmap);
+    return;
+  }
+  if (rowmap) {
+    // the 64 x 64 kernel has no gather / scatter of the rows: running it would write the rows of C to the wrong problems.  The one
+    // caller with a rowmap (the device tail's x_unc rows) only exists on the 128-grid (`lazy`); anything else is a bug -- say so.
+    set_error("gemm64: rowmap with a shape off the 128 x 128 / K %% 16 grid (M = %d, N = %d, K = %d)", M, N, K);
+    h->gemm_error = true;
     return;
   }
   dim3 grid(N / 64, M / 64);
@@ -962,7 +999,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   AsmDev a;
   a.Kunc = h->Kunc64; a.Wx = Wx; a.winit = winit;
   a.ffU = a.ffVx = a.ffVl = a.ffcu = nullptr; a.ffk = nullptr; a.ffr = a.ffW = 0; a.T = h->asm_xhw; a.tnorm = h->asm_tnorm; a.tslack = h->asm_tslack;
-  a.ff_skip = 0; a.ff_err = 0.0;
+  a.ff_skip = 0; a.ff_err = 0.0; a.ff_efar = 0.0;
   static const bool no_far = getenv("NNMPC_NO_FARFIELD") != nullptr;      // diagnostics: dense form of the full-width pass (A/B)
   int wide_far_rp = 0, fft_prev = 0;
   double wide_far_ksum = 0.0;                      // the last full-width pass ran in the far-field form with this padded rank
@@ -1069,11 +1106,11 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
           if (!ff && h->far_missing.size() < 16 && std::find(h->far_missing.begin(), h->far_missing.end(), c0) == h->far_missing.end())
             h->far_missing.push_back(c0);                // (the host wrapper may add the factors for this window: nnmpc_qp_farfield_missing)
         }
-        a.ff_err = 0.0; a.ff_skip = 0; wide_far_rp = 0;
+        a.ff_err = 0.0; a.ff_efar = 0.0; a.ff_skip = 0; wide_far_rp = 0;
         if (ff) {
           // far-field form: T = [x0 | lamw] V, x[c0:] = T U'; first-move calls skip the column tiles |U_j| |T_p| certifies
           a.ffU = ff->U; a.ffVx = ff->Vx; a.ffVl = ff->Vl; a.ffcu = ff->cu; a.ffk = ff->kt; a.ffr = ff->rp; a.ffW = ff->W;
-          a.ff_err = h->p_inf * ff->efar;
+          a.ff_err = h->p_inf * ff->efar; a.ff_efar = ff->efar;
           a.ff_skip = h->nout <= c0 && h->nout < h->n;
           wide_far_rp = ff->rp; wide_far_ksum = ff->ksum;
           h->stats.asm_far_passes += 1;
@@ -1258,6 +1295,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(stream_sync(s));
   }
+  if (h->gemm_error) { h->gemm_error = false; return NNMPC_EINVAL; }
   if (!defer_cnt) h->stats.asm_full_checks += cnt[ASM_CNT_DONE];
   if (defer_cnt || cnt[ASM_CNT_DONE] > 0) {                // (row blocks without an ASM_DONE row leave these GEMMs at once)
     gemm64(h, h->q64_all, h->np, h->x0_64, h->ka, h->tq64, h->ka, segp, h->np, h->ka, h->asm_state, ASM_DONE);
@@ -1418,7 +1456,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.rd, V); A_(d.rhs, V); A_(d.sol, V); A_(d.dua, V); A_(d.dvec, V); A_(d.mask, V); A_(d.uunc, V);
   A_(d.x, V); A_(d.q64, V); A_(d.PX, V); A_(d.r64, V); A_(d.p64, V); A_(d.v64, V); A_(d.st, V);
   A_(d.phase, S); A_(d.f_factor, S); A_(d.f_solve, S); A_(d.istep, S); A_(d.ipm_it, S);
-  A_(d.nfac, S); A_(d.prounds, S); A_(d.pninf, S); A_(d.pgrace, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.stale, S); A_(d.rz, S);
+  A_(d.nfac, S); A_(d.prounds, S); A_(d.pninf, S); A_(d.pgrace, S); A_(d.ptie, S); A_(d.rcnt, S); A_(d.psub, S); A_(d.fail, S); A_(d.stale, S); A_(d.rz, S);
   A_(d.mu, S); A_(d.gap, S); A_(d.smu, S); A_(d.qscale, S); A_(d.counters, 8);
   {
     // segment size: as many problems as a quarter of the free HBM allows (per problem: q f64, warm start f32 and the
@@ -1523,6 +1561,7 @@ int nnmpc_qp_destroy(nnmpc_qp* h) {
   if (!h) return NNMPC_OK;
   hipDeviceSynchronize();
   for (void* p : h->allocs) hipFree(p);
+  for (auto& g : h->far) { hipFree(g.U); hipFree(g.Vx); hipFree(g.Vl); hipFree(g.cu); hipFree(g.kt); }
   for (auto& sc : h->sc) if (sc.p) hipFree(sc.p);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1643,35 +1682,42 @@ int nnmpc_qp_set_farfield(nnmpc_qp* h, int32_t W, int32_t r, const double* U, co
   }
   nnmpc_qp::Far f;
   f.W = W; f.r = r; f.rp = rp; f.U = f.Vx = f.Vl = f.cu = nullptr; f.kt = nullptr; f.ksum = ksum; f.efar = 0.0;
-  int rc = 0;
-  if (!rc) rc = dev_alloc(h, &f.U, u.size());
-  if (!rc) rc = dev_alloc(h, &f.Vx, vx.size());
-  if (!rc) rc = dev_alloc(h, &f.Vl, vl.size());
-  if (!rc) rc = dev_alloc(h, &f.cu, cu.size());
-  if (!rc) rc = dev_alloc(h, &f.kt, kt.size());
-  if (rc) return rc;
-  HIPCHK(hipMemcpy(f.kt, kt.data(), kt.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(f.U, u.data(), u.size() * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(f.Vx, vx.data(), vx.size() * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(f.Vl, vl.data(), vl.size() * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(f.cu, cu.data(), cu.size() * 8, hipMemcpyHostToDevice));
+  // the factors' buffers are owned by their Far entry (not by the handle's allocation list): a refused set and a replaced one are
+  // released at once
+  unsigned long long* em = nullptr;
+  auto release = [&](nnmpc_qp::Far& g) {
+    hipFree(g.U); hipFree(g.Vx); hipFree(g.Vl); hipFree(g.cu); hipFree(g.kt);
+    g.U = g.Vx = g.Vl = g.cu = nullptr; g.kt = nullptr;
+  };
+  auto fail = [&](int code) { release(f); if (em) hipFree(em); return code; };
+#define FFCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e_)); return fail(e_ == hipErrorOutOfMemory ? NNMPC_ENOMEM : NNMPC_EHIP); } } while (0)
+  FFCHK(hipMalloc((void**)&f.U, u.size() * 8));
+  FFCHK(hipMalloc((void**)&f.Vx, vx.size() * 8));
+  FFCHK(hipMalloc((void**)&f.Vl, vl.size() * 8));
+  FFCHK(hipMalloc((void**)&f.cu, cu.size() * 8));
+  FFCHK(hipMalloc((void**)&f.kt, kt.size() * sizeof(int)));
+  FFCHK(hipMemcpy(f.kt, kt.data(), kt.size() * sizeof(int), hipMemcpyHostToDevice));
+  FFCHK(hipMemcpy(f.U, u.data(), u.size() * 8, hipMemcpyHostToDevice));
+  FFCHK(hipMemcpy(f.Vx, vx.data(), vx.size() * 8, hipMemcpyHostToDevice));
+  FFCHK(hipMemcpy(f.Vl, vl.data(), vl.size() * 8, hipMemcpyHostToDevice));
+  FFCHK(hipMemcpy(f.cu, cu.data(), cu.size() * 8, hipMemcpyHostToDevice));
   // ---- verify on the device copies the passes will use: max |U [Vx | Vl] - [Kunc[W:] | -Pinv[W:, 0:W]]|
   {
-    unsigned long long* em = nullptr;
-    HIPCHK(hipMalloc((void**)&em, 8));
-    HIPCHK(hipMemset(em, 0, 8));
+    FFCHK(hipMalloc((void**)&em, 8));
+    FFCHK(hipMemset(em, 0, 8));
     hipLaunchKernelGGL(far_verify_k, dim3(nf), dim3(256), rp * sizeof(double), h->stream, f.U, f.Vx, f.Vl, h->Kunc64, h->H64, W, rp, ka, np, em);
     unsigned long long bits = 0;
-    HIPCHK(hipMemcpyAsync(&bits, em, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(stream_sync(h->stream));
-    hipFree(em);
+    FFCHK(hipMemcpyAsync(&bits, em, 8, hipMemcpyDeviceToHost, h->stream));
+    FFCHK(stream_sync(h->stream));
+    hipFree(em); em = nullptr;
     double e;
     memcpy(&e, &bits, 8);
     f.efar = e;
-    if (!(e < 1e-9)) { set_error("nnmpc_qp_set_farfield: max |U V' - M| = %.3e: the factors are not usable", e); return NNMPC_EINVAL; }
+    if (!(e < 1e-9)) { set_error("nnmpc_qp_set_farfield: max |U V' - M| = %.3e: the factors are not usable", e); return fail(NNMPC_EINVAL); }
   }
+#undef FFCHK
   h->far_missing.erase(std::remove(h->far_missing.begin(), h->far_missing.end(), W), h->far_missing.end());
-  for (auto& g : h->far) if (g.W == W) { g = f; return NNMPC_OK; }   // (replaces; the old copies stay allocated until destroy)
+  for (auto& g : h->far) if (g.W == W) { HIPCHK(stream_sync(h->stream)); release(g); g = f; return NNMPC_OK; }   // replaces the window's factors
   h->far.push_back(f);
   return NNMPC_OK;
 }

@@ -189,15 +189,21 @@ static __global__ __launch_bounds__(256) void asm_wide_tnorm_k(AsmDev d, int ntm
   if (row >= ntm * 128) return;
   const int p = d.rowprob[row];
   const bool ok = p >= 0;
-  double s = 0.0, sl = 1e300;
+  double s = 0.0, sl = 1e300, z1 = 0.0;
   if (ok) {
     for (int k = lane; k < d.ffr; k += 64) { const double t = d.T[(size_t)row * d.ffr + k]; s += t * t; }
     for (int k = lane; k < d.nu; k += 64) sl = fmin(sl, fmin(d.ub[(size_t)p * d.nu + k], -d.lb[(size_t)p * d.nu + k]));
+    // |z|_1 = |x0|_1 + |lam|_1: the factored product is off from M z by at most ff_efar |z|_1 per entry (far_verify_k's bound)
+    for (int k = lane; k < d.ka; k += 64) z1 += fabs(d.x0[(size_t)p * d.ka + k]);
+    const int m = d.mg[p];
+    const int* idx = d.idxg + (size_t)p * d.max_active;
+    for (int i = lane; i < m; i += 64) z1 += fabs(d.lam[(size_t)row * d.np + idx[i]]);
   }
-  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); sl = fmin(sl, __shfl_xor(sl, off)); }
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); sl = fmin(sl, __shfl_xor(sl, off)); z1 += __shfl_xor(z1, off); }
   if (lane == 0) {
     d.tnorm[row] = ok ? sqrt(s) * (1.0 + 1e-12) : 0.0;       // rows without a problem never ask for a tile
-    d.tslack[row] = ok ? sl - d.bound_tol : 1e300;           // (a NaN bound or T entry fails "<=": the tile is evaluated)
+    // |x_j| <= |U_j| |T_p| + ff_efar |z|_1 must stay inside the box shrunk by the feasibility tolerance
+    d.tslack[row] = ok ? sl - d.bound_tol - d.ff_efar * z1 * (1.0 + 1e-12) : 1e300;   // (a NaN bound or T entry fails "<=": the tile is evaluated)
   }
 }
 

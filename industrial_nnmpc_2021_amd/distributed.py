@@ -23,15 +23,25 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_T_START = time.time()            # this process's start, near enough (the module is imported before any communicator exists)
+
+
 def job_key():
-    """Key of the rendezvous file, the same on every rank of ONE job and different between jobs: a nonce the launcher
-    generated (``NNMPC_JOB_KEY``: bench.py's self-launch exports a uuid4; ``TORCHELASTIC_RUN_ID`` under torch.distributed.run
-    when it is not the default "none").  Without either -- ranks started by hand -- MASTER_PORT + the parent's pid has to do
-    (weak: two jobs of one shell on the default port share it; such a key's file is additionally required to be fresh)."""
-    nonce = os.environ.get("NNMPC_JOB_KEY") or os.environ.get("TORCHELASTIC_RUN_ID", "")
+    """Key of the rendezvous file, the same on every rank of ONE launch and different between launches: a nonce the launcher
+    generated.  ``NNMPC_JOB_KEY`` (bench.py's self-launch exports a fresh uuid4 per launch) is taken as it is.
+    ``TORCHELASTIC_RUN_ID`` (torch.distributed.run, when not the default "none") is NOT fresh by itself -- the id survives elastic
+    restarts and a user-set --rdzv-id survives whole runs -- so TORCHELASTIC_RESTART_COUNT and the pid of the elastic agent (the
+    common parent of the ranks of a node) go into the key with it: a restarted or repeated job looks at another path.  Without
+    either -- ranks started by hand -- MASTER_PORT + the parent's pid has to do (weak).  Whatever the key, a reader only accepts a
+    file written after it started itself (exchange_unique_id)."""
     port = os.environ.get("MASTER_PORT", "0")
-    if nonce and nonce != "none":
-        return "".join(ch if ch.isalnum() else "_" for ch in nonce)[:64] + "_" + port, True
+    clean = lambda t: "".join(ch if ch.isalnum() else "_" for ch in t)[:64]
+    nonce = os.environ.get("NNMPC_JOB_KEY", "")
+    if nonce:
+        return clean(nonce) + "_" + port, True
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    if run_id and run_id != "none":
+        return f"{clean(run_id)}_r{clean(os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'))}_p{os.getppid()}_{port}", True
     return f"{port}_{os.getppid()}", False
 
 
@@ -39,15 +49,57 @@ def _uid_path(key):
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nnmpc_uid_{os.getuid()}_{key}")
 
 
-def exchange_unique_id(rank, world, key, make_id, timeout_s=120.0, strong_key=True):
+_CLEANUP = set()                  # rendezvous files this process (rank 0) wrote and has not removed yet
+
+
+def _cleanup_files(*_a):
+    for path in list(_CLEANUP):
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        _CLEANUP.discard(path)
+
+
+def _install_cleanup():
+    """Rank 0 removes its rendezvous file on any exit it can see (normal exit, SIGTERM): a file left behind by a rank 0 that died
+    inside ncclCommInitRank is what a later launch with a recycled key would otherwise trip over."""
+    import atexit
+    import signal
+    if getattr(_install_cleanup, "done", False):
+        return
+    _install_cleanup.done = True
+    atexit.register(_cleanup_files)
+    try:
+        prev = signal.getsignal(signal.SIGTERM)
+
+        def on_term(signum, frame):
+            _cleanup_files()
+            if callable(prev):
+                prev(signum, frame)
+            else:
+                signal.signal(signal.SIGTERM, signal.SIG_DFL)
+                os.kill(os.getpid(), signal.SIGTERM)
+        signal.signal(signal.SIGTERM, on_term)
+    except (ValueError, OSError):                      # not the main thread: atexit has to do
+        pass
+
+
+FRESH_SLACK_S = 120.0             # a usable id was written no earlier than this long before the reader started
+
+
+def exchange_unique_id(rank, world, key, make_id, timeout_s=120.0, strong_key=True, t_start=None):
     """The 128-byte RCCL unique id of rank 0 reaches the other ranks through a file under $TMPDIR (all ranks of a job are
-    on ONE node).  ``key`` must be the same on every rank and unique to the job (``job_key()``).
+    on ONE node).  ``key`` must be the same on every rank and unique to the launch (``job_key()``).
 
     Rank 0 removes whatever sits at the path (a leftover of a killed job with a recycled key), writes a private temporary
     (O_EXCL | O_NOFOLLOW, mode 0600) and renames it into place: readers see all 128 bytes or no file, and a pre-created
-    symlink is replaced, not followed.  Readers take only a regular file of 128 bytes that this user owns with mode 0600
-    -- and, under a weak key, one written in the last few minutes: a stale id would send ncclCommInitRank into a rendezvous
-    nobody else attends, and RCCL has no timeout."""
+    symlink is replaced, not followed; it removes the file again at exit / on SIGTERM (and, normally, as soon as every rank has
+    joined: Comm.__init__).  Readers OPEN first (O_NOFOLLOW) and check the descriptor they will read from -- a regular file of
+    128 bytes that this user owns with mode 0600, written no earlier than FRESH_SLACK_S before this reader started, for
+    strong and weak keys alike: a stale id would send ncclCommInitRank into a rendezvous nobody else attends, and RCCL has no
+    timeout.  (``strong_key`` is kept for callers; it no longer relaxes any check.)"""
+    import stat as _stat
     path = _uid_path(key)
     if rank == 0:
         uid = make_id()
@@ -61,25 +113,28 @@ def exchange_unique_id(rank, world, key, make_id, timeout_s=120.0, strong_key=Tr
             os.write(fd, uid)
         finally:
             os.close(fd)
+        _install_cleanup()
+        _CLEANUP.add(path)
         os.replace(tmp, path)
         return uid
+    t_ref = _T_START if t_start is None else t_start
     t0 = time.time()
     while time.time() - t0 < timeout_s:
+        fd = -1
         try:
-            st = os.lstat(path)
-            import stat as _stat
+            fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0) | getattr(os, "O_NONBLOCK", 0))
+            st = os.fstat(fd)                          # the object that is read, not whatever the path names a moment later
             ok = (_stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0 and st.st_size == 128
-                  and (strong_key or st.st_mtime >= t0 - 300.0))
+                  and st.st_mtime >= t_ref - FRESH_SLACK_S)
             if ok:
-                fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
-                try:
-                    uid = os.read(fd, 129)
-                finally:
-                    os.close(fd)
+                uid = os.read(fd, 129)
                 if len(uid) == 128:
                     return uid
-        except (FileNotFoundError, OSError):
+        except OSError:                                # not there yet, a symlink (ELOOP), not ours to open
             pass
+        finally:
+            if fd >= 0:
+                os.close(fd)
         time.sleep(0.01)
     raise TimeoutError(f"rank {rank}: no usable RCCL unique id at {path} after {timeout_s} s")
 
@@ -108,10 +163,7 @@ class Comm:
         _lib.check(lib.nnmpc_comm_init(C.byref(self._h), C.c_char_p(uid), self.rank, self.world), "nnmpc_comm_init")
         if self._path and self.rank == 0:
             self.barrier()                          # everybody has read the id: the file can go
-            try:
-                os.remove(self._path)
-            except OSError:
-                pass
+            _cleanup_files()
         elif self._path:
             self.barrier()
 

@@ -122,8 +122,14 @@ class BatchedBoxQP:
         # far-field form of the full-width pass (include/nnmpc.h: nnmpc_qp_set_farfield): "auto" factors the far block
         # for a window the first time a call's full-width pass had to do without (one-time host setup like the inverse:
         # an fp64 SVD, ~1.5 s at the CDU size); a list of windows factors them now; None / False never
-        self._ff_src = (Hinv, Kunc) if (self.have_inverse and farfield) else None
+        # (kept for those factorisations: the leading half of the columns of P^-1 and Kunc -- a window beyond n / 2 cannot pay --,
+        # 80 of the 160 MB at the CDU size; released by close())
+        self._ff_wmax = (n // 2 // 128) * 128
+        self._ff_src = (np.ascontiguousarray(Hinv[:, :self._ff_wmax]), Kunc) if (self.have_inverse and farfield and self._ff_wmax > 0) else None
+        nb_lib = nb if nb else (128 if n > 1024 else 64)     # the library pads n to its tile size (nnmpc_qp_create)
+        self._np = -(-n // nb_lib) * nb_lib
         self._ff_done = set()
+        self.farfield_info = {}        # window -> dict(rank, tiles' K extents ...) of the factors handed to the library (0: not usable)
         if self._ff_src is not None and not isinstance(farfield, str):
             for W in farfield:
                 self.prepare_farfield(int(W))
@@ -143,14 +149,17 @@ class BatchedBoxQP:
         if self._ff_src is None or W in self._ff_done:
             return 0
         self._ff_done.add(W)
+        self.farfield_info[W] = dict(rank=0, reason="window not on the 128-column grid")
         Hinv, Kunc = self._ff_src
-        if W <= 0 or W % 128 or W >= self.n or self.n % 128:
+        if W <= 0 or W % 128 or W >= self.n or self._np % 128 or W > self._ff_wmax:   # (the library's own gate is on the PADDED n)
             return 0
         import scipy.linalg as sla
         M = np.hstack((Kunc[W:], -Hinv[W:, :W]))
         U, s, Vt = sla.svd(M, full_matrices=False, lapack_driver="gesdd")
         r = max(1, int((s > rtol * s[0]).sum()))
         rp, nf, k = -(-r // 128) * 128, self.n - W, -(-self.n_aug // 32) * 32 + W
+        self.farfield_info[W] = dict(rank=0, numerical_rank=r, sigma_ratio_at_rank=float(s[min(r, s.size - 1)] / s[0]),
+                                     reason="the factored form would not pay: numerical rank too large")
         if rp * (k + nf) > 0.8 * k * nf:             # the factored form would not pay (the library refuses such factors too):
             return 0                                 # a generic Hessian's far block has full rank, the MPC structure makes it ~Nx
         Uf, G = _staircase(U[:, :r] * s[:r], rtol * s[0])
@@ -161,9 +170,12 @@ class BatchedBoxQP:
         rc = self._lib.nnmpc_qp_set_farfield(self._h, W, r, p(Uf), p(Vx), p(Vl))
         if rc == _lib.EINVAL:                        # refused (rank too large for the workspace, factors too inaccurate): dense form stays
             import warnings
-            warnings.warn("BatchedBoxQP.prepare_farfield: " + self._lib.nnmpc_last_error().decode(errors="replace"), RuntimeWarning)
+            self.farfield_info[W] = dict(rank=0, numerical_rank=r, reason=self._lib.nnmpc_last_error().decode(errors="replace"))
+            warnings.warn("BatchedBoxQP.prepare_farfield: " + self.farfield_info[W]["reason"], RuntimeWarning)
             return 0
         _lib.check(rc, "nnmpc_qp_set_farfield")
+        kj = [int(np.flatnonzero(np.abs(Uf[j:j + 128]).max(axis=0) > 0).max(initial=-1)) + 1 for j in range(0, Uf.shape[0], 128)]
+        self.farfield_info[W] = dict(rank=int(r), staircase_mean_k=float(np.mean(kj)), staircase_max_k=int(max(kj)))
         return r
 
     def _farfield_auto(self):

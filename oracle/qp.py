@@ -138,7 +138,13 @@ def solve_exact(P, q, G, h, tol=1e-10, maxiters=60, info=None):
         if max(np.max(np.abs(rx)), np.max(np.abs(rz)), gap) <= tol:
             break
         d = z / s
-        F = sla.cho_factor(P + G.T @ (d[:, None] * G), lower=True)
+        try:
+            F = sla.cho_factor(P + G.T @ (d[:, None] * G), lower=True)
+        except np.linalg.LinAlgError:
+            # z / s spans ~1e+-10 near the end; with an ill-conditioned dense G (the re-parameterised regulator at the CDU size:
+            # cond(G'G) ~ 1e5) the reduced KKT matrix then loses positivity in fp64.  The iterate is good enough to name the
+            # active set: the polish below starts from it, and the KKT residuals reported in `info` judge the result.
+            break
         mu, sigma, dsa, dza = gap / m, 0.0, None, None
         for i in (0, 1):
             rc = -s * z + sigma * mu - (dsa * dza if i else 0.0)

@@ -38,33 +38,42 @@ def oracle_solve(reg, x0, lb, ub):
     return U, act
 
 
-_JOB = None
-
-
-def _oracle_box_row(arg):
-    r, threads = arg
-    Ps, tq, nu, N, x0, lb, ub = _JOB
-
-    def run():
-        info = {"nu": nu}
-        xe = oqp.solve_exact_box(Ps, tq @ x0[r], np.tile(lb[r], N), np.tile(ub[r], N), info=info)
-        return xe, info["active"]
-    if threads:
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=threads):
-            return run()
-    return run()
-
-
 def oracle_box_rows(Ps, tq, nu, N, x0, lb, ub, rows):
-    """[(u*, active rows of G)] of the listed problems by oracle.qp.solve_exact_box, in forked workers (the solves are
-    independent and take seconds each at the CDU size; the workers inherit the matrices and never touch the GPU)."""
-    import multiprocessing as mp
+    """[(u*, active rows of G)] of the listed problems by oracle.qp.solve_exact_box.  At the CDU size a solve takes seconds, so
+    the rows are shared out over worker PROCESSES -- started as fresh interpreters (`python -m tests.oracle_worker`), never
+    forked: a child forked from a process that has touched the GPU inherits the KFD descriptors and objects whose __del__ calls
+    into the runtime (undefined behaviour on ROCm).  Matrices and results travel as .npz files under /dev/shm."""
     import os
-    global _JOB
-    _JOB = (Ps, tq, nu, N, x0, lb, ub)
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    rows = [int(r) for r in rows]
     nw = max(1, min(16, len(rows), (os.cpu_count() or 1) // 4))
     if nw == 1 or Ps.shape[0] < 1024:
-        return [_oracle_box_row((int(r), 0)) for r in rows]
-    with mp.get_context("fork").Pool(nw) as pool:
-        return pool.map(_oracle_box_row, [(int(r), max(1, (os.cpu_count() or 1) // (2 * nw))) for r in rows])
+        out = []
+        for r in rows:
+            info = {"nu": nu}
+            xe = oqp.solve_exact_box(Ps, tq @ x0[r], np.tile(lb[r], N), np.tile(ub[r], N), info=info)
+            out.append((xe, info["active"]))
+        return out
+    keep = np.array(sorted(set(rows)), dtype=int)           # only the listed rows travel (the batch can be hundreds of MB)
+    sub = {int(r): i for i, r in enumerate(keep)}
+    d = tempfile.mkdtemp(prefix="nnmpc_test_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        np.savez(os.path.join(d, "job.npz"), Ps=Ps, tq=tq, nu=nu, N=N, x0=x0[keep], lb=lb[keep], ub=ub[keep])
+        threads = max(1, (os.cpu_count() or 1) // (2 * nw))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        procs = [subprocess.Popen([sys.executable, "-m", "tests.oracle_worker", d, str(w), str(nw)], cwd=root, env=env) for w in range(nw)]
+        codes = [p.wait() for p in procs]
+        if any(codes):
+            raise RuntimeError(f"oracle worker exit codes {codes}")
+        res = {}
+        for w in range(nw):
+            with np.load(os.path.join(d, f"out{w}.npz"), allow_pickle=False) as f:
+                for i in f["rows"]:
+                    res[int(i)] = (f[f"x{i}"], f[f"a{i}"])
+        return [res[sub[r]] for r in rows]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

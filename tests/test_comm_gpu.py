@@ -45,6 +45,7 @@ def test_bench_rank_code_with_forced_communicator():
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["solver"]["status_hist"][0] == 4096
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["status_hist"][0] == 4096
     assert line["parity"]["active_set_hamming"] == 0 and line["parity"]["max_rel_err_vs_fp64_oracle"] < 1e-8
     assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    assert len(r.stdout.strip().splitlines()[-1]) < 4096

@@ -137,13 +137,29 @@ def test_rendezvous_file_is_private_fresh_and_not_followed(tmp_path, monkeypatch
     assert stat.S_ISREG(st.st_mode) and (st.st_mode & 0o777) == 0o600 and st.st_size == 128
     assert dd.exchange_unique_id(1, 2, key, None, timeout_s=2.0) == uid
     old = time.time() - 3600
-    os.utime(path, (old, old))                                        # a leftover of a killed job with the same (weak) key
-    with pytest.raises(TimeoutError):
-        dd.exchange_unique_id(1, 2, key, None, timeout_s=0.3, strong_key=False)
-    assert dd.exchange_unique_id(1, 2, key, None, timeout_s=2.0, strong_key=True) == uid      # a nonce key needs no freshness test
+    os.utime(path, (old, old))                                        # a leftover of a killed job that recycled the key
+    for strong in (False, True):                                      # stale is stale, whatever the key: a torchrun id is reused across
+        with pytest.raises(TimeoutError):                             # elastic restarts and with a user-set --rdzv-id
+            dd.exchange_unique_id(1, 2, key, None, timeout_s=0.3, strong_key=strong)
+    assert dd.exchange_unique_id(1, 2, key, None, timeout_s=2.0, t_start=old) == uid   # (a reader that started back then takes it)
+    os.utime(path, None)
     os.chmod(path, 0o644)
     with pytest.raises(TimeoutError):
         dd.exchange_unique_id(1, 2, key, None, timeout_s=0.3)
+    os.chmod(path, 0o600)
+    # the checks run on the descriptor that is read: a path swapped for a symlink to a same-sized file of another kind is not followed
+    other = tmp_path / "other"
+    other.write_bytes(bytes(128))
+    os.chmod(other, 0o600)
+    os.remove(path)
+    os.symlink(other, path)
+    with pytest.raises(TimeoutError):
+        dd.exchange_unique_id(1, 2, key, None, timeout_s=0.3)
+    os.remove(path)
+    # rank 0 takes its file away at exit / SIGTERM (and Comm.__init__ as soon as every rank has joined)
+    assert dd.exchange_unique_id(0, 2, key, lambda: uid) == uid and os.path.exists(path) and path in dd._CLEANUP
+    dd._cleanup_files()
+    assert not os.path.exists(path) and not dd._CLEANUP
     monkeypatch.setenv("NNMPC_JOB_KEY", "abc-123")
     monkeypatch.setenv("MASTER_PORT", "29511")
     assert dd.job_key() == ("abc_123_29511", True)
@@ -151,6 +167,13 @@ def test_rendezvous_file_is_private_fresh_and_not_followed(tmp_path, monkeypatch
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
     k, strong = dd.job_key()
     assert not strong and k.startswith("29511_")
+    # a torchrun id alone is not fresh: restart count and the agent's pid are part of the key
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "my-job")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    k0, strong = dd.job_key()
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    k1, _ = dd.job_key()
+    assert strong and k0 != k1 and f"_p{os.getppid()}_" in k0 and k0.startswith("my_job_r0_")
 
 
 def _dataset_worker(rank, world, port, out):
