@@ -78,6 +78,9 @@ typedef struct {
   int32_t asm_tail_batch;    /* a call (segment) of at most this many problems is finished on the device from the start
                                 (asm_tail_k, one workgroup per problem, no lock-step rounds): the chains of a task, a
                                 controller's single QP; 0 = 256 (the most the kernel's slabs hold), < 0 = never */
+  int32_t asm_predict_iters; /* iterations of the dual accelerated-projected-gradient predictor that names the FIRST active sets of
+                                the rounds (bf16 MFMA, csrc/qp_predict.h): 0 = 24, < 0 = off (first sets = the bounds x_unc violates).
+                                Affects only the number of rounds, never a result; used when n >= 512, nu <= 64, no caller's guess */
   float ipm_tol;             /* PDIP exit, objective scaled by 1/median(diag P):
                                 |r_d|_inf and mu <= tol*max(1,|q|_inf); 0 = 1e-2 */
   double refine_tol;         /* PCG exit: |step|_inf <= tol*max(1,|x|_inf); 0 = 1e-10 */
@@ -116,6 +119,9 @@ typedef struct {
   double asm_side_ms;        /* hipEvent time of the multiplier kernels of the larger sets on the three side streams (they run
                                 beside asm_lambda_reg32_k / asm_lambda_reg_k; sum over the streams) */
   int64_t asm_small_passes;  /* segments that went through the one-wave-per-problem kernel of small problems (asm_small_k: n <= 724) */
+  int64_t asm_predict_launches; /* launches of the first-set predictor (asm_predict_k) */
+  double asm_predict_ms;     /* their hipEvent time (profiling on) */
+  double asm_predict_flops;  /* bf16 MFMA flops they executed: 2 * 64 * 512 * (columns of Y in use) per workgroup and iteration */
 } nnmpc_qp_stats;
 
 const char* nnmpc_last_error(void);

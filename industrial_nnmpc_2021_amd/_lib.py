@@ -16,7 +16,7 @@ class QpOpts(C.Structure):
                 ("max_polish_rounds", C.c_int32), ("max_refine", C.c_int32),
                 ("max_rounds", C.c_int32), ("sub_steps", C.c_int32), ("stale_max_changes", C.c_int32),
                 ("stale_cg_limit", C.c_int32), ("method", C.c_int32), ("asm_max_active", C.c_int32),
-                ("asm_max_rounds", C.c_int32), ("asm_f32_rounds", C.c_int32), ("seg_max", C.c_int32), ("asm_tail_batch", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
+                ("asm_max_rounds", C.c_int32), ("asm_f32_rounds", C.c_int32), ("seg_max", C.c_int32), ("asm_tail_batch", C.c_int32), ("asm_predict_iters", C.c_int32), ("ipm_tol", C.c_float), ("refine_tol", C.c_double),
                 ("bound_tol", C.c_double)]
 
 
@@ -31,7 +31,8 @@ class QpStats(C.Structure):
                 ("asm_e2max", C.c_double), ("asm_full_checks", C.c_int64), ("asm_lambda32_ms", C.c_double),
                 ("asm_lambda64_ms", C.c_double), ("asm_lambda32_flops", C.c_double),
                 ("asm_lambda32_launches", C.c_int64), ("asm_lambda64_launches", C.c_int64), ("asm_far_passes", C.c_int64), ("asm_side_ms", C.c_double),
-                ("asm_small_passes", C.c_int64)]
+                ("asm_small_passes", C.c_int64), ("asm_predict_launches", C.c_int64), ("asm_predict_ms", C.c_double),
+                ("asm_predict_flops", C.c_double)]
 
 
 EXPORTS = ["nnmpc_last_error", "nnmpc_qp_create", "nnmpc_qp_destroy", "nnmpc_qp_solve_batch",

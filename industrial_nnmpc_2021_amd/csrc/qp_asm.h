@@ -74,6 +74,7 @@ struct AsmDev {
   const double* x0;                // [nseg][ka] padded initial states (for the certificate; first K segment of the full-width pass)
   int ka;
   const double* Kunc;              // [np][ka]: x_unc = Kunc x0
+  int pred_w;                      // bound states of the columns [0, pred_w) were named by asm_predict_k (qp_predict.h): asm_init_k leaves them
   int winit;                       // columns the first sets are drawn from (without a guess): the leading eighth of the horizon, 512 at least
   int Wx;                          // x_unc exists in HBM for the columns [0, Wx) only (Wx = np: all of them); beyond, the full-width
                                    // pass forms it inside its GEMM (qp_wide.h), the rare consumers below from Kunc and x0
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d, int nrows) {
   const int wi = d.guess ? d.n : min(d.n, d.winit);
   const bool kfix = 64 % d.nu == 0;                          // k = r % nu is then the same for every chunk of 64 columns
   const double lbf = d.lb[(size_t)p * d.nu + lane % d.nu], ubf = d.ub[(size_t)p * d.nu + lane % d.nu];
-  for (int r = lane; r < wi; r += 64) {
+  for (int r = (d.guess ? 0 : d.pred_w) + lane; r < wi; r += 64) {
     int s = 0;
     if (d.guess) { s = d.guess[(size_t)p * d.n + r]; if (s > 2) s = 0; }
     else {

@@ -30,6 +30,7 @@
 #include "qp_asm.h"
 #include "qp_wide.h"
 #include "qp_small.h"
+#include "qp_predict.h"
 #include "common.h"
 
 using namespace nnmpc;
@@ -710,6 +711,10 @@ struct nnmpc_qp {
   std::vector<int> far_missing;   // windows of full-width passes that ran in the dense form for want of factors (handed out once each)
   double p_inf = 0.0;       // max row sum of |P|
   double *asm_tnorm = nullptr, *asm_tslack = nullptr;
+  // first-set predictor (qp_predict.h): bf16 fragments of Pinv[0:512, 0:512], step sizes; set by nnmpc_qp_set_inverse when the problem is large enough
+  pu32x4* pred_Hf = nullptr;
+  float* pred_tt = nullptr;
+  double pred_L = 0.0;          // lambda_max(D^-1/2 Pinv_WW D^-1/2)
   double* asm_work;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
   double* x0_64;        // [seg_max][ka]
@@ -807,6 +812,7 @@ void ev_collect(nnmpc_qp* h) {
     else if (r.kind == 7) { h->stats.asm_lambda32_ms += ms; h->stats.asm_lambda32_launches += 1; }
     else if (r.kind == 8) { h->stats.asm_lambda64_ms += ms; h->stats.asm_lambda64_launches += 1; }
     else if (r.kind == 9) h->stats.asm_side_ms += ms;
+    else if (r.kind == 10) { h->stats.asm_predict_ms += ms; h->stats.asm_predict_launches += 1; h->stats.asm_predict_flops += r.flops; }
   }
   h->ev_recs.clear();
   h->ev_used = 0;
@@ -1019,6 +1025,24 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
   // asm_update_k / asm_wide_k of the same round
   if (!guess_dev) HIPCHK(hipMemsetAsync(h->asm_st, 0, (size_t)nprob * h->n, s));   // bound states: asm_init_k writes the leading window only
+  // first sets: named by the dual projected-gradient predictor inside its window (qp_predict.h), by the bounds x_unc violates beyond
+  // it (and everywhere when the predictor is off, the problem small, or the caller brought a guess)
+  a.pred_w = 0;
+  {
+    static const int env_it = getenv("NNMPC_PRED_ITERS") ? atoi(getenv("NNMPC_PRED_ITERS")) : -1;   // (the variable: diagnostics, A/B; 0 = off)
+    const int iters = env_it >= 0 ? std::min(env_it, (int)PRED_MAXIT) : h->opts.asm_predict_iters;
+    if (iters > 0 && h->pred_L > 0.0 && !guess_dev && !small && !tail_only && Wx >= PRED_W) {
+      PredArgs pa;
+      pa.Hf = h->pred_Hf; pa.tt = h->pred_tt; pa.iters = iters;
+      double t = 1.0;
+      for (int k = 0; k < iters; ++k) { const double tn = 0.5 * (1.0 + std::sqrt(1.0 + 4.0 * t * t)); pa.beta[k] = (float)((t - 1.0) / tn); t = tn; }
+      for (int k = iters; k < PRED_MAXIT; ++k) pa.beta[k] = 0.f;
+      // (flops: an upper bound -- the K loop of an iteration stops at the last column of Y in use)
+      EvScope es(h, 10, 2.0 * PRED_W * (double)PRED_W * (double)(iters - 1) * (double)(((nprob + 63) / 64) * 64));
+      hipLaunchKernelGGL(asm_predict_k, dim3((nprob + 63) / 64), dim3(64 * PRED_NW), pred_lds_bytes(h->nu), s, a, pa);
+      a.pred_w = PRED_W;
+    }
+  }
   hipLaunchKernelGGL(asm_init_k, dim3((segp + 3) / 4), dim3(256), 0, s, a, segp);
   const int lds_big = (a.max_active + ASM_TS) * 8;
   int* cnt = h->pin_cnt;
@@ -1401,6 +1425,8 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   // problems of the reference's regime settle within 40 iterations and never see the difference)
   h->asm_tail_budget = o.asm_max_rounds <= 0 ? 50000 : o.asm_max_rounds;
   if (o.asm_max_rounds <= 0) o.asm_max_rounds = 200;
+  if (o.asm_predict_iters == 0) o.asm_predict_iters = 24;
+  if (o.asm_predict_iters > PRED_MAXIT) o.asm_predict_iters = PRED_MAXIT;
   if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
   if (o.refine_tol <= 0.0) o.refine_tol = 1e-10;
@@ -1598,6 +1624,57 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
     HIPCHK(hipMemcpy(h->H32, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
+  // ---- first-set predictor (qp_predict.h): bf16 MFMA fragments of the leading PRED_W x PRED_W block, the diagonal step sizes
+  // t_j = 1 / (L Pinv_jj) with L = lambda_max(D^-1/2 Pinv_WW D^-1/2) (power iteration, 5 % margin: a step that is a little short
+  // costs nothing but speed)
+  h->pred_L = 0.0;
+  if (np >= PRED_W && n >= PRED_W && h->nu <= 64 && h->nu % 4 == 0 && h->opts.asm_predict_iters > 0) {
+    const int W = PRED_W;
+    std::vector<double> dg(W);
+    bool okd = true;
+    for (int j = 0; j < W; ++j) { dg[j] = hh[(size_t)j * np + j]; okd = okd && dg[j] > 0.0; }
+    if (okd) {
+      std::vector<double> v(W, 1.0), u(W);
+      double lam = 0.0;
+      for (int itp = 0; itp < 200; ++itp) {
+        double nv = 0.0;
+        for (int i = 0; i < W; ++i) nv += v[i] * v[i];
+        nv = std::sqrt(nv);
+        for (int i = 0; i < W; ++i) v[i] /= nv;
+        for (int i = 0; i < W; ++i) {
+          double sacc = 0.0;
+          const double* hr = &hh[(size_t)i * np];
+          for (int j = 0; j < W; ++j) sacc += hr[j] * v[j] / std::sqrt(dg[j]);
+          u[i] = sacc / std::sqrt(dg[i]);
+        }
+        double num = 0.0;
+        for (int i = 0; i < W; ++i) num += u[i] * v[i];
+        const bool conv = std::fabs(num - lam) <= 1e-6 * std::fabs(num);
+        lam = num;
+        v = u;
+        if (conv && itp > 8) break;
+      }
+      if (lam > 0.0 && lam == lam) {
+        h->pred_L = 1.05 * lam;
+        std::vector<float> tt(2 * W);
+        for (int j = 0; j < W; ++j) { tt[j] = (float)(1.0 / (h->pred_L * dg[j])); tt[W + j] = (float)(h->pred_L * dg[j]); }
+        std::vector<unsigned short> hf((size_t)W * W);
+        auto bf = [](double x) { float f = (float)x; unsigned u32; memcpy(&u32, &f, 4); return (unsigned short)((u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16); };
+        for (int jt = 0; jt < W / 16; ++jt)
+          for (int ks = 0; ks < PRED_KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int li = lane & 15, lq = lane >> 4;
+              for (int e = 0; e < 8; ++e)
+                hf[pred_frag_index(jt, ks, lane) * 8 + e] = bf(hh[(size_t)(16 * jt + li) * np + 32 * ks + 8 * lq + e]);
+            }
+        if (!h->pred_Hf) { int rc = dev_alloc(h, (unsigned short**)&h->pred_Hf, hf.size()); if (rc) return rc; }
+        if (!h->pred_tt) { int rc = dev_alloc(h, &h->pred_tt, tt.size()); if (rc) return rc; }
+        HIPCHK(hipMemcpy(h->pred_Hf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->pred_tt, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes(h->nu)));
+      }
+    }
+  }
   // ---- verify the inverse once, on the device copies the solves will use:
   //      E2 = P Pinv - I,  E1 = P Kunc + tq;  their maxima feed the per-problem certificate
   {

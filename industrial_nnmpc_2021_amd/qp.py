@@ -69,7 +69,7 @@ class BatchedBoxQP:
 
     def __init__(self, P, tq, nu, *, Kunc="auto", method="auto", farfield="auto", max_batch=1024, nb=0, ipm_tol=0.0,
                  max_rounds=0, max_ipm_iters=0, max_polish_rounds=0, max_refine=0, sub_steps=0, stale_max_changes=0, stale_cg_limit=0, asm_max_active=0,
-                 asm_max_rounds=0, asm_f32_rounds=0, seg_max=0, asm_tail_batch=0):
+                 asm_max_rounds=0, asm_f32_rounds=0, seg_max=0, asm_tail_batch=0, asm_predict_iters=0):
         lib = _lib.load()
         P = np.ascontiguousarray(P, dtype=np.float64)
         tq = np.ascontiguousarray(tq, dtype=np.float64)
@@ -99,6 +99,7 @@ class BatchedBoxQP:
                            max_rounds=max_rounds, sub_steps=sub_steps, stale_max_changes=stale_max_changes,
                            stale_cg_limit=stale_cg_limit, method=meth, asm_max_active=asm_max_active,
                            asm_max_rounds=asm_max_rounds, asm_f32_rounds=asm_f32_rounds, seg_max=seg_max, asm_tail_batch=asm_tail_batch,
+                           asm_predict_iters=asm_predict_iters,
                            ipm_tol=ipm_tol, refine_tol=0.0, bound_tol=0.0)
         self._h = C.c_void_p()
         kp = Kunc.ctypes.data_as(C.c_void_p) if Kunc is not None else None
@@ -177,6 +178,13 @@ class BatchedBoxQP:
         kj = [int(np.flatnonzero(np.abs(Uf[j:j + 128]).max(axis=0) > 0).max(initial=-1)) + 1 for j in range(0, Uf.shape[0], 128)]
         self.farfield_info[W] = dict(rank=int(r), staircase_mean_k=float(np.mean(kj)), staircase_max_k=int(max(kj)))
         return r
+
+    def prepare_farfield_windows(self, lo=512, hi=None):
+        """Factor every window lo, lo + 128, ... <= hi (default: a quarter of the horizon) now -- one-time setup like the inverse,
+        ~0.5 s of host SVD and ~10 MB of HBM per window at the CDU size -- so that no later call meets a window without factors
+        (the window of a call follows its batch: the last active bound of any of its problems).  Returns {W: rank}."""
+        hi = self.n // 4 if hi is None else hi
+        return {W: self.prepare_farfield(W) for W in range(lo, hi + 1, 128)}
 
     def _farfield_auto(self):
         if self._ff_src is None:
