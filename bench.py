@@ -1001,6 +1001,7 @@ def unstable_leg(ctx, B=16384, steps=3, sx=1.5):
     nu, n = reg.Nu, Pw.shape[0]
     qp = BatchedBoxQP(Pw, tqw, nu, max_batch=1024)
     t_setup = time.perf_counter() - t0
+    qp.prepare_farfield_windows()                      # (one-time setup; on this plant every window is refused: see the docstring)
     nsets = steps + 2
     sets = []
     for i in range(nsets):

@@ -75,6 +75,7 @@ struct AsmDev {
   int ka;
   const double* Kunc;              // [np][ka]: x_unc = Kunc x0
   int pred_w;                      // bound states of the columns [0, pred_w) were named by asm_predict_k (qp_predict.h): asm_init_k leaves them
+  int pred_f64;                    // ... and the rounds start in fp64 (a predicted set is close to the final one: an f32 round would mostly confirm it)
   int winit;                       // columns the first sets are drawn from (without a guess): the leading eighth of the horizon, 512 at least
   int Wx;                          // x_unc exists in HBM for the columns [0, Wx) only (Wx = np: all of them); beyond, the full-width
                                    // pass forms it inside its GEMM (qp_wide.h), the rare consumers below from Kunc and x0
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d, int nrows) {
   // an empty set runs one round like the others: x = x_unc is checked and certified by asm_update_k / asm_wide_k
   if (lane == 0) {
     d.rounds[p] = 0; d.state[p] = invalid ? ASM_INVALID : ASM_RUN;
-    d.prec[p] = (d.use_f32 && !d.guess) ? 0 : 1;       // a caller's guess is expected to be right: confirm it in fp64 at once
+    d.prec[p] = (d.use_f32 && !d.guess && !(d.pred_w && d.pred_f64)) ? 0 : 1;   // a caller's guess (a predicted set) is expected to be right: fp64 at once
     d.redo[p] = 0;
     d.ninf_best[p] = 0x7fffffff; d.alpha[p] = ASM_GRACE;
     d.hi[p] = wi;

@@ -10,6 +10,9 @@
 //      x   = x_unc - H y                                  (MFMA: Y[rows][W] x H[W][W], bf16 operands, f32 accumulate)
 //      v   = y + t x,    mu+ = v - clip(v, t lb, t ub)     (the prox of t sigma_box: exact, elementwise)
 //      y+  = mu+ + beta_k (mu+ - mu)                      (Nesterov momentum)
+// The kernel iterates on the SCALED multiplier nu = mu / t (t is fixed, so it is the same iteration): with H' = H diag(t) as the MFMA
+// operand,  x = x_unc - H' y,  w = y + x,  nu+ = w - clip(w, lb, ub),  y+ = nu+ + beta (nu+ - nu)  -- no multiplication by t left
+// in the elementwise part, and a w inside the box gives an EXACT zero (w - w): the sign of nu is what names the set.
 // does not have to CONVERGE: it only has to name the active set.  Measured on the CDU plant (CPU emulation, bf16 operands
 // change nothing): Hamming distance of the predicted set from the final one 67 (x_unc start) -> 5.5 after 12 iterations, 2.8
 // after 20, 0.9 after 30; rounds until the set stops moving 4.6 -> 2.3 / 2.1 / 1.6 (sx = 2); 5.9 -> 2.6 at sx = 4 (217 bounds).
@@ -37,6 +40,9 @@ typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int pu32x2 __attribute__((ext_vector_type(2)));
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pbf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PRED_NT = 4;                   // 16-column tiles per wave
 constexpr int PRED_NW = 8;                   // waves per workgroup
@@ -46,15 +52,14 @@ constexpr int PRED_LDY = PRED_W + 8;         // bf16 per row of Y: 16 B of paddi
 constexpr int PRED_MAXIT = 64;
 
 struct PredArgs {
-  const pu32x4* Hf;      // [NW waves][KS][NT][64] fragments of bf16(H[0:W, 0:W]): lane (li, lq) of (w, ks, jt) holds H[16 (w NT + jt) + li][32 ks + 8 lq .. + 8]
+  const pu32x4* Hf;      // [NW waves][KS][NT][64] fragments of bf16(H'[0:W, 0:W]), H' = H diag(t), t_k = 1 / (L H_kk): lane (li, lq) of (w, ks, jt) holds H[16 (w NT + jt) + li][32 ks + 8 lq .. + 8]
                          // (the NT fragments a wave needs for one k-step are 4 KB of consecutive memory: pred_frag_index)
-  const float* tt;       // [2][W]: t_j = 1 / (L H_jj), then 1 / t_j
   int iters;
   float beta[PRED_MAXIT];   // momentum of iteration k (beta[0] = 0)
 };
 
 __host__ __device__ constexpr int pred_lds_bytes(int nu) {
-  return 64 * PRED_LDY * 2 + 2 * PRED_W * 4 + 2 * 64 * (nu + 4) * 4 + 16;      // (nu a multiple of 4)
+  return 64 * PRED_LDY * 2 + 2 * 64 * (nu + 4) * 4 + 16;      // (nu a multiple of 4)
 }
 
 __host__ __device__ constexpr size_t pred_frag_index(int jtg, int ks, int lane) {   // 16-byte fragment of column tile jtg (0 .. W / 16), k-step ks
@@ -70,16 +75,13 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
   extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
   constexpr int NT = PRED_NT, W = PRED_W, KS = PRED_KS, LDY = PRED_LDY;
   unsigned short* Y = reinterpret_cast<unsigned short*>(sm_raw);              // [64][LDY] bf16 patterns
-  float* tl = reinterpret_cast<float*>(Y + 64 * LDY);                          // [2][W]
   const int ldb = d.nu + 4;                                                    // (rows 16 B aligned; 16 rows of a float4 read hit distinct banks for nu = 32)
-  float* lbs = tl + 2 * W;                                                     // [64][nu + 4]
+  float* lbs = reinterpret_cast<float*>(Y + 64 * LDY);                         // [64][nu + 4]
   float* ubs = lbs + 64 * ldb;
-  int* kmx = reinterpret_cast<int*>(ubs + 64 * ldb);                           // [2] last non-zero column of Y (double-buffered by iteration parity)
   constexpr int NTH = 64 * PRED_NW;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int p0 = blockIdx.x * 64;
-  for (int i = tid; i < 2 * W; i += NTH) tl[i] = a.tt[i];
   for (int i = tid; i < 64 * d.nu; i += NTH) {
     const int r = i / d.nu, k = i - r * d.nu;
     const size_t p = (size_t)min(p0 + r, d.nseg - 1);
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
     ubs[r * ldb + k] = (float)d.ub[p * d.nu + k];
   }
   for (int i = tid; i < 64 * LDY / 2; i += NTH) reinterpret_cast<unsigned*>(Y)[i] = 0u;
-  if (tid < 2) kmx[tid] = -1;
-  // ---- state: x_unc (f16, high half) | mu (bf16, low half); element (jt, pt, r): problem 16 pt + li, column 16 (w NT + jt) + 4 lq + r
-  unsigned s[NT][4][4];
+  // ---- state, in pairs of consecutive columns (packed f32 arithmetic, v_cvt_pk_bf16_f32): sx = x_unc as two f16, sm = mu as two bf16;
+  // pair (jt, pt, h): problem 16 pt + li, columns 16 (w NT + jt) + 4 lq + 2 h, + 1
+  unsigned sx[NT][4][2], sm[NT][4][2];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -97,15 +99,18 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
       const size_t p = (size_t)min(p0 + 16 * pt + li, d.nseg - 1);
       const double* xr = d.xunc + p * d.np + 16 * (w * NT + jt) + 4 * lq;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float xu = fminf(fmaxf((float)xr[r], -60000.f), 60000.f);          // (f16 range; a NaN stays a NaN: that problem is rejected elsewhere)
-        s[jt][pt][r] = ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)xu) << 16);
+      for (int h = 0; h < 2; ++h) {
+        // (f16 range; a NaN stays a NaN: that problem is rejected elsewhere)
+        const pf32x2 xu = {fminf(fmaxf((float)xr[2 * h], -60000.f), 60000.f), fminf(fmaxf((float)xr[2 * h + 1], -60000.f), 60000.f)};
+        sx[jt][pt][h] = __builtin_bit_cast(unsigned, __builtin_convertvector(xu, pf16x2));
+        sm[jt][pt][h] = 0u;
       }
     }
   int kc0[NT];                                                                 // input index of the first of a lane's four columns
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) kc0[jt] = (16 * (w * NT + jt) + 4 * lq) % d.nu;
   const bool st_words = (d.n & 3) == 0;
+  const bool per32 = 32 % d.nu == 0;                                           // (uniform)
   __syncthreads();
   // this wave's fragments by BUFFER loads: the lane's 16 bytes are a loop-invariant vector offset, (w KS + ks) NT + jt KB go into the
   // scalar offset -- one address register for all loads (hipcc turned global loads into one hoisted 64-bit address PER LOAD: 128
@@ -123,85 +128,92 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) acc[jt][pt] = pf32x4{0.f, 0.f, 0.f, 0.f};
-    const int kl = kmx[it & 1];                                                  // (uniform: written before the last barrier)
-    if (tid == 0) kmx[(it + 1) & 1] = -1;                                        // (last read an iteration ago; visible after the barrier below)
-    const int kend = min(KS, ((kl + 32) >> 5));                                  // k-steps that hold a non-zero y
-    const int kend4 = (kend + 3) & ~3;
-    if (kend4 > 0) {
-      pu32x4 hb[4][NT];                                                          // ring of four k-steps of H fragments (loads three steps ahead)
-      asm_sfor<0, 3>([&](auto bc) __attribute__((always_inline)) {
+    // (all KS k-steps: the multipliers of the CDU batch reach column ~480 of 512 -- stopping at the last non-zero column of Y saved one
+    // step in sixteen and cost a conditional per group of steps; iteration 0 has y = 0 and skips the phase)
+#ifdef PRED_NO_MFMA
+    if (false) {
+#else
+    if (it > 0) {
+#endif
+      constexpr int RD = 3;                                                      // ring of three k-steps of H fragments: loads two steps ahead
+      pu32x4 hb[RD][NT];
+      asm_sfor<0, RD - 1>([&](auto bc) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) hb[b][jt] = hload(b, jt);
       });
-      // (straight-line code over the KS k-steps, left in whole groups of four: every buffer index is a constant and the wait counts
-      // of the loads in flight are exact)
-      asm_sfor<0, KS / 4>([&](auto gc) __attribute__((always_inline)) {
-        constexpr int ks0 = 4 * decltype(gc)::value;
-        if (ks0 < kend4) {
-          asm_sfor<0, 4>([&](auto bc) __attribute__((always_inline)) {
-            constexpr int b = decltype(bc)::value, ks = ks0 + b;
-            constexpr int kn = ks + 3 < KS ? ks + 3 : KS - 1;                    // (a clamped reload is never multiplied)
+      // (straight-line code over the KS k-steps: every buffer index is a constant and the wait counts of the loads in flight are exact)
+      asm_sfor<0, KS>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(kc)::value, b = ks % RD;
+        if constexpr (ks + RD - 1 < KS) {
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) hb[(b + 3) & 3][jt] = hload(kn, jt);
-            pu32x4 yf[4];
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) yf[pt] = *reinterpret_cast<const pu32x4*>(Y + (16 * pt + li) * LDY + 32 * ks + 8 * lq);
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-              for (int pt = 0; pt < 4; ++pt)
-                acc[jt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8, hb[b][jt]), __builtin_bit_cast(pbf16x8, yf[pt]),
-                                                                      acc[jt][pt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);                                   // (one k-step per scheduling region: bounded live ranges)
-          });
+          for (int jt = 0; jt < NT; ++jt) hb[(ks + RD - 1) % RD][jt] = hload(ks + RD - 1, jt);
         }
+        pu32x4 yf[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) yf[pt] = *reinterpret_cast<const pu32x4*>(Y + (16 * pt + li) * LDY + 32 * ks + 8 * lq);
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt)
+            acc[jt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8, hb[b][jt]), __builtin_bit_cast(pbf16x8, yf[pt]),
+                                                                  acc[jt][pt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                                       // (one k-step per scheduling region: bounded live ranges)
       });
     }
     __syncthreads();                                                             // every wave is done reading Y
     // ---- prox step, momentum, Y rewritten in place (each lane owns its elements)
-    const float beta = a.beta[it];
+    const pf32x2 beta2 = {a.beta[it], a.beta[it]};
     const bool last = it + 1 == a.iters;
-    int kmax = -1;
+    // (per-lane bases of the LDS accesses below, hidden from the optimiser once per iteration: left alone it hoists ~50 loop-invariant
+    // addresses out of the iteration loop and keeps them in scratch memory; from these bases every address is an immediate offset)
+    unsigned short* Yl = Y + li * LDY + 64 * w + 4 * lq;
+    const float* lbl = lbs + li * ldb;
+    const float* ubl = ubs + li * ldb;
+    asm volatile("" : "+v"(Yl), "+v"(lbl), "+v"(ubl));
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-      const int c0 = 16 * (w * NT + jt) + 4 * lq;
-      const pf32x4 t4 = *reinterpret_cast<const pf32x4*>(tl + c0);
-      bool nz = false;
+    for (int pt = 0; pt < 4; ++pt) {
+      // (nu is a multiple of 4 and so is the lane's first column: its four columns are four consecutive inputs of one stage; when nu
+      // divides 32 the column tiles jt and jt + 2 see the same inputs: their bounds are read once)
+      pf32x4 lb4[2], ub4[2];
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
-        unsigned short* yp = Y + (16 * pt + li) * LDY + c0;
+      for (int jt = 0; jt < NT; ++jt) {
+        if (jt < 2 || !per32) {
+          lb4[jt & 1] = *reinterpret_cast<const pf32x4*>(lbl + 16 * pt * ldb + kc0[jt]);
+          ub4[jt & 1] = *reinterpret_cast<const pf32x4*>(ubl + 16 * pt * ldb + kc0[jt]);
+        }
+        unsigned short* yp = Yl + 16 * pt * LDY + 16 * jt;
         const pu32x2 yw = *reinterpret_cast<const pu32x2*>(yp);
-        // (nu is a multiple of 4 and so is the lane's first column: its four columns are four consecutive inputs of one stage)
-        const pf32x4 lb4 = *reinterpret_cast<const pf32x4*>(lbs + (16 * pt + li) * ldb + kc0[jt]);
-        const pf32x4 ub4 = *reinterpret_cast<const pf32x4*>(ubs + (16 * pt + li) * ldb + kc0[jt]);
-        unsigned yb[4];
+        unsigned yb[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned sv = s[jt][pt][r];
-          const float xu = (float)__builtin_bit_cast(_Float16, (unsigned short)(sv >> 16));
-          const float mu = __uint_as_float(sv << 16);
-          const float y = __uint_as_float((r & 1) ? (yw[r >> 1] & 0xffff0000u) : (yw[r >> 1] << 16));
-          const float x = xu - acc[jt][pt][r];
-          const float v = fmaf(t4[r], x, y);
-          // prox of t sigma_box:  v - t clip(v / t, lb, ub) = v - clip(v, t lb, t ub)  -- in THIS form a v inside the scaled box gives an
-          // exact zero (v - v); through v / t the rounding leaves +-1e-8 of either sign, and the sign is what names the set
-          const float mun = v - fminf(fmaxf(v, t4[r] * lb4[r]), t4[r] * ub4[r]);
-          const float yn = fmaf(beta, mun - mu, mun);
-          yb[r] = pred_bf16(yn);
-          s[jt][pt][r] = (sv & 0xffff0000u) | pred_bf16(mun);
-          nz |= yb[r] != 0u && yb[r] != 0x8000u;
+        for (int h = 0; h < 2; ++h) {
+          const pf32x2 xu = __builtin_convertvector(__builtin_bit_cast(pf16x2, sx[jt][pt][h]), pf32x2);
+          const unsigned mw = sm[jt][pt][h], ywd = yw[h];
+          const pf32x2 nu = {__uint_as_float(mw << 16), __uint_as_float(mw & 0xffff0000u)};
+          const pf32x2 y = {__uint_as_float(ywd << 16), __uint_as_float(ywd & 0xffff0000u)};
+          const pf32x2 ac = {acc[jt][pt][2 * h], acc[jt][pt][2 * h + 1]};
+#ifdef PRED_NO_EPI
+          const pf32x2 wv = xu - ac;
+#else
+          const pf32x2 wv = y + (xu - ac);
+#endif
+          // prox of sigma_box in the scaled variable:  w - clip(w, lb, ub)  (the clip as a median of three: one instruction; lb <= ub,
+          // else the problem is rejected elsewhere)
+          const pf32x2 cl = {__builtin_amdgcn_fmed3f(wv[0], lb4[jt & 1][2 * h], ub4[jt & 1][2 * h]),
+                             __builtin_amdgcn_fmed3f(wv[1], lb4[jt & 1][2 * h + 1], ub4[jt & 1][2 * h + 1])};
+          const pf32x2 nun = wv - cl;
+          const pf32x2 yn = beta2 * (nun - nu) + nun;
+          yb[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(yn, pbf16x2));
+          sm[jt][pt][h] = __builtin_bit_cast(unsigned, __builtin_convertvector(nun, pbf16x2));
           if (last) {                                                           // the predicted set: the sign of the multiplier
-            // (mun itself, not its bf16 image; exact zeros come out of the projection)
-            acc[jt][pt][r] = mun;
+            // (nun itself, not its bf16 image; exact zeros come out of the projection)
+            acc[jt][pt][2 * h] = nun[0]; acc[jt][pt][2 * h + 1] = nun[1];
           }
         }
-        *reinterpret_cast<pu32x2*>(yp) = pu32x2{yb[0] | (yb[1] << 16), yb[2] | (yb[3] << 16)};
+        *reinterpret_cast<pu32x2*>(yp) = pu32x2{yb[0], yb[1]};
       }
-      if (__any(nz)) kmax = 16 * (w * NT + jt) + 15;
-      __builtin_amdgcn_sched_barrier(0);                                         // (one column tile per scheduling region)
+      __builtin_amdgcn_sched_barrier(0);                                         // (one row tile per scheduling region)
     }
-    if (lane == 0 && kmax >= 0) atomicMax(&kmx[(it + 1) & 1], kmax);
     if (last) {
       // ---- bound states of the window: 1 upper (mu > 0), 2 lower (mu < 0), 0 free
 #pragma unroll
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
         }
       }
     }
-    __syncthreads();                                                             // Y and kmx of the next iteration are complete
+    __syncthreads();                                                             // Y of the next iteration is complete
   }
 }
 

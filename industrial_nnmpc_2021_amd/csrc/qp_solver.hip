@@ -713,7 +713,6 @@ struct nnmpc_qp {
   double *asm_tnorm = nullptr, *asm_tslack = nullptr;
   // first-set predictor (qp_predict.h): bf16 fragments of Pinv[0:512, 0:512], step sizes; set by nnmpc_qp_set_inverse when the problem is large enough
   pu32x4* pred_Hf = nullptr;
-  float* pred_tt = nullptr;
   double pred_L = 0.0;          // lambda_max(D^-1/2 Pinv_WW D^-1/2)
   double* asm_work;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
@@ -1027,13 +1026,13 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   if (!guess_dev) HIPCHK(hipMemsetAsync(h->asm_st, 0, (size_t)nprob * h->n, s));   // bound states: asm_init_k writes the leading window only
   // first sets: named by the dual projected-gradient predictor inside its window (qp_predict.h), by the bounds x_unc violates beyond
   // it (and everywhere when the predictor is off, the problem small, or the caller brought a guess)
-  a.pred_w = 0;
+  a.pred_w = 0; a.pred_f64 = 0;
   {
     static const int env_it = getenv("NNMPC_PRED_ITERS") ? atoi(getenv("NNMPC_PRED_ITERS")) : -1;   // (the variable: diagnostics, A/B; 0 = off)
     const int iters = env_it >= 0 ? std::min(env_it, (int)PRED_MAXIT) : h->opts.asm_predict_iters;
     if (iters > 0 && h->pred_L > 0.0 && !guess_dev && !small && !tail_only && Wx >= PRED_W) {
       PredArgs pa;
-      pa.Hf = h->pred_Hf; pa.tt = h->pred_tt; pa.iters = iters;
+      pa.Hf = h->pred_Hf; pa.iters = iters;
       double t = 1.0;
       for (int k = 0; k < iters; ++k) { const double tn = 0.5 * (1.0 + std::sqrt(1.0 + 4.0 * t * t)); pa.beta[k] = (float)((t - 1.0) / tn); t = tn; }
       for (int k = iters; k < PRED_MAXIT; ++k) pa.beta[k] = 0.f;
@@ -1041,6 +1040,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       EvScope es(h, 10, 2.0 * PRED_W * (double)PRED_W * (double)(iters - 1) * (double)(((nprob + 63) / 64) * 64));
       hipLaunchKernelGGL(asm_predict_k, dim3((nprob + 63) / 64), dim3(64 * PRED_NW), pred_lds_bytes(h->nu), s, a, pa);
       a.pred_w = PRED_W;
+      { static const int pf = getenv("NNMPC_PRED_F64") ? atoi(getenv("NNMPC_PRED_F64")) : 0; a.pred_f64 = pf; }   // (the variable: diagnostics, A/B)
     }
   }
   hipLaunchKernelGGL(asm_init_k, dim3((segp + 3) / 4), dim3(256), 0, s, a, segp);
@@ -1193,9 +1193,10 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       }
     }
     if (nrun == 0) break;
-    if (nrun <= std::min(h->asm_pool, 256) && (rounds >= 6 || small)) {
+    if (nrun <= std::min(h->asm_pool, 256) && (rounds >= (a.pred_w ? 2 : 6) || small)) {
       // the tail: a handful of stragglers (the bulk settles in 5-8 rounds) -- finish them on the device (asm_tail_k)
-      // instead of paying eight launches and a read-back per round for them.  From round 6 on (12 before: at 100 000
+      // instead of paying eight launches and a read-back per round for them.  From round 6 on -- from round 2 when the first sets
+      // were predicted (qp_predict.h: the bulk then settles in rounds 1-2, and rounds 3-4 were 0.9 ms for 130 problems) -- (12 before: at 100 000
       // problems per call the rounds 7..12 were launches for a few dozen problems, 5 % of the step)
       EvScope es(h, 4, 0.0);
       hipLaunchKernelGGL(asm_taillist_k, dim3((nprob + 255) / 256), dim3(256), 0, s, a);
@@ -1624,8 +1625,8 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
     HIPCHK(hipMemcpy(h->H32, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
-  // ---- first-set predictor (qp_predict.h): bf16 MFMA fragments of the leading PRED_W x PRED_W block, the diagonal step sizes
-  // t_j = 1 / (L Pinv_jj) with L = lambda_max(D^-1/2 Pinv_WW D^-1/2) (power iteration, 5 % margin: a step that is a little short
+  // ---- first-set predictor (qp_predict.h): bf16 MFMA fragments of the leading PRED_W x PRED_W block, scaled by the diagonal step sizes
+  // t_k = 1 / (L Pinv_kk) (H' = H diag(t)) with L = lambda_max(D^-1/2 Pinv_WW D^-1/2) (power iteration, 5 % margin: a step that is a little short
   // costs nothing but speed)
   h->pred_L = 0.0;
   if (np >= PRED_W && n >= PRED_W && h->nu <= 64 && h->nu % 4 == 0 && h->opts.asm_predict_iters > 0) {
@@ -1656,8 +1657,8 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
       }
       if (lam > 0.0 && lam == lam) {
         h->pred_L = 1.05 * lam;
-        std::vector<float> tt(2 * W);
-        for (int j = 0; j < W; ++j) { tt[j] = (float)(1.0 / (h->pred_L * dg[j])); tt[W + j] = (float)(h->pred_L * dg[j]); }
+        std::vector<double> tcol(W);
+        for (int j = 0; j < W; ++j) tcol[j] = 1.0 / (h->pred_L * dg[j]);
         std::vector<unsigned short> hf((size_t)W * W);
         auto bf = [](double x) { float f = (float)x; unsigned u32; memcpy(&u32, &f, 4); return (unsigned short)((u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16); };
         for (int jt = 0; jt < W / 16; ++jt)
@@ -1665,12 +1666,10 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
             for (int lane = 0; lane < 64; ++lane) {
               const int li = lane & 15, lq = lane >> 4;
               for (int e = 0; e < 8; ++e)
-                hf[pred_frag_index(jt, ks, lane) * 8 + e] = bf(hh[(size_t)(16 * jt + li) * np + 32 * ks + 8 * lq + e]);
+                hf[pred_frag_index(jt, ks, lane) * 8 + e] = bf(hh[(size_t)(16 * jt + li) * np + 32 * ks + 8 * lq + e] * tcol[32 * ks + 8 * lq + e]);   // H' = H diag(t)
             }
         if (!h->pred_Hf) { int rc = dev_alloc(h, (unsigned short**)&h->pred_Hf, hf.size()); if (rc) return rc; }
-        if (!h->pred_tt) { int rc = dev_alloc(h, &h->pred_tt, tt.size()); if (rc) return rc; }
         HIPCHK(hipMemcpy(h->pred_Hf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->pred_tt, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes(h->nu)));
       }
     }

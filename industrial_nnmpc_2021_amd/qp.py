@@ -179,7 +179,7 @@ class BatchedBoxQP:
         self.farfield_info[W] = dict(rank=int(r), staircase_mean_k=float(np.mean(kj)), staircase_max_k=int(max(kj)))
         return r
 
-    def prepare_farfield_windows(self, lo=512, hi=None):
+    def prepare_farfield_windows(self, lo=128, hi=None):
         """Factor every window lo, lo + 128, ... <= hi (default: a quarter of the horizon) now -- one-time setup like the inverse,
         ~0.5 s of host SVD and ~10 MB of HBM per window at the CDU size -- so that no later call meets a window without factors
         (the window of a call follows its batch: the last active bound of any of its problems).  Returns {W: rank}."""

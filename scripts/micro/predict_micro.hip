@@ -38,10 +38,8 @@ int main(int argc, char** argv) {
     v = u;
   }
   const double L = 1.05 * lam;
-  std::vector<float> tt(2 * W);
-  for (int j = 0; j < W; ++j) { tt[j] = (float)(1.0 / (L * H[(size_t)j * W + j])); tt[W + j] = (float)(L * H[(size_t)j * W + j]); }
   std::vector<unsigned short> hf((size_t)W * W), hb((size_t)W * W);
-  for (size_t i = 0; i < hb.size(); ++i) hb[i] = bfh((float)H[i]);
+  for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) hb[(size_t)j * W + k] = bfh((float)(H[(size_t)j * W + k] * (1.0 / (L * H[(size_t)k * W + k]))));   // H' = H diag(t)
   for (int jt = 0; jt < W / 16; ++jt)
     for (int ks = 0; ks < PRED_KS; ++ks)
       for (int lane = 0; lane < 64; ++lane)
@@ -52,15 +50,14 @@ int main(int argc, char** argv) {
   for (int p = 0; p < nseg; ++p) for (int k = 0; k < nu; ++k) { lb[(size_t)p * nu + k] = -1.0 - 0.3 * fabs(g(rng)); ub[(size_t)p * nu + k] = 1.0 + 0.3 * fabs(g(rng)); }
   AsmDev d{};
   d.n = n; d.np = np; d.nu = nu; d.nseg = nseg;
-  double *dx, *dlb, *dub; unsigned char* dst; pu32x4* dHf; float* dtt;
+  double *dx, *dlb, *dub; unsigned char* dst; pu32x4* dHf;
   CK(hipMalloc(&dx, xunc.size() * 8)); CK(hipMemcpy(dx, xunc.data(), xunc.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dlb, lb.size() * 8)); CK(hipMemcpy(dlb, lb.data(), lb.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dub, ub.size() * 8)); CK(hipMemcpy(dub, ub.data(), ub.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dst, (size_t)nseg * n)); CK(hipMemset(dst, 0, (size_t)nseg * n));
   CK(hipMalloc(&dHf, hf.size() * 2)); CK(hipMemcpy(dHf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
-  CK(hipMalloc(&dtt, tt.size() * 4)); CK(hipMemcpy(dtt, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
   d.xunc = dx; d.lb = dlb; d.ub = dub; d.st = dst;
-  PredArgs pa; pa.Hf = dHf; pa.tt = dtt; pa.iters = iters;
+  PredArgs pa; pa.Hf = dHf; pa.iters = iters;
   { double t = 1.0; for (int k = 0; k < PRED_MAXIT; ++k) { const double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t)); pa.beta[k] = k < iters ? (float)((t - 1.0) / tn) : 0.f; t = tn; } }
   CK(hipFuncSetAttribute((const void*)asm_predict_k, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes(nu)));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -84,9 +81,9 @@ int main(int argc, char** argv) {
     for (int it = 0; it < iters; ++it) {
       for (int j = 0; j < W; ++j) { double s = 0; for (int k = 0; k < W; ++k) s += (double)bff(hb[(size_t)j * W + k]) * (double)y[k]; x[j] = xu[j] - (float)s; }
       for (int j = 0; j < W; ++j) {
-        const float t = tt[j];
-        const float vv = fmaf(t, x[j], y[j]);
-        const float mun = vv - fminf(fmaxf(vv, t * (float)lb[(size_t)p * nu + j % nu]), t * (float)ub[(size_t)p * nu + j % nu]);
+        const float wv = y[j] + x[j];
+        const float lo = (float)lb[(size_t)p * nu + j % nu], hi = (float)ub[(size_t)p * nu + j % nu];
+        const float mun = wv - fminf(fmaxf(wv, lo), hi);
         const float yn = fmaf(pa.beta[it], mun - mu[j], mun);
         y[j] = bff(bfh(yn));
         if (it + 1 == iters) { const int sref = mun > 0.f ? 1 : (mun < 0.f ? 2 : 0); diff += sref != st[(size_t)p * n + j]; act += sref != 0; ++tot; }
