@@ -544,6 +544,9 @@ def compact_line(out, detail_path=None):
     if "roofline_gemm_group" in out:
         g = out["roofline_gemm_group"]
         line["roofline_gemm_group"] = {k: _num(g.get(k), 4) for k in ("dtype", "achieved", "peak", "frac", "time_share", "traffic")}
+    if "roofline_predictor" in out:
+        g = out["roofline_predictor"]
+        line["roofline_predictor"] = {k: _num(g.get(k), 4) for k in ("dtype", "achieved", "peak", "frac", "time_share", "traffic")}
     if "roofline_step" in out:
         rs = out["roofline_step"]
         line["roofline_step"] = {"frac": _num(rs.get("frac"), 4), "ideal_ms_per_step": _num(rs.get("ideal_ms_per_step"), 4),
@@ -709,6 +712,18 @@ def bench_qp(ctx, workload, B, steps, warmup, sx, method="auto", slots=0, seed0=
                                 "(PMC passes of scripts/pmc_hbm.sh); algorithmic_bytes_per_step = x0, bounds in + u* out"}
         fam = multiplier_family(st, traffic)
         inst = lambda_rooflines(st, traffic)
+        pred = None
+        if st["asm_predict_ms"] > 0:
+            # first-set predictor (qp_predict.h): bf16 MFMA, f32 accumulate; flops = the dense count 2 W^2 per problem and iteration
+            pach = st["asm_predict_flops"] / (st["asm_predict_ms"] * 1e-3) / 1e12
+            trp, trp_step, _ = _traffic_of(traffic, ["asm_predict_k"])
+            pred = {"kernel": "asm_predict_k: dual accelerated projected gradient on the window (x = x_unc - H' y on v_mfma_f32_16x16x32_bf16, prox + momentum "
+                              "elementwise), 64 problems per workgroup for all iterations, H' (512 KB bf16) streamed from L2 once per iteration",
+                    "dtype": "bf16", "bound": "mfma", "achieved": pach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pach / BF16_PEAK_TFLOPS,
+                    "traffic": trp, "traffic_per_step": trp_step, "launches": int(st["asm_predict_launches"]),
+                    "avg_launch_ms": st["asm_predict_ms"] / max(1, st["asm_predict_launches"]), "time_share": st["asm_predict_ms"] / st["total_ms"],
+                    "algorithmic_flops": "2 * 512 * 512 per problem and iteration after the first (bf16 operands, f32 accumulate); the kernel is co-limited by "
+                                         "the L2 -> CU stream of H' (512 KB per workgroup and iteration: 39 TB/s over the chip at the MFMA-bound rate)"}
         small = None
         if st["asm_small_passes"]:
             # small problems (n <= 724): the whole iteration runs in asm_small_k, one wave per problem (qp_small.h) -- a chain of L2 round
@@ -731,6 +746,8 @@ def bench_qp(ctx, workload, B, steps, warmup, sx, method="auto", slots=0, seed0=
         res["roofline"] = fams[0]
         res["roofline_gemm_group"] = gemm
         res["roofline_multiplier_instances"] = inst
+        if pred:
+            res["roofline_predictor"] = pred
         if small and fam:
             res["roofline_multiplier_family"] = fam
         res["roofline"]["traffic_unit"] = "HBM bytes per launch; " + tnote
@@ -738,16 +755,17 @@ def bench_qp(ctx, workload, B, steps, warmup, sx, method="auto", slots=0, seed0=
         # the whole step against the roofline: every part's algorithmic flops at the peak of its own number type / the step's time
         f32l = st["asm_lambda32_flops"]
         ideal_ms = 1e3 * (st["asm_gemm_flops"] / (FP64_PEAK_TFLOPS * 1e12) + f32l / (FP32_PEAK_TFLOPS * 1e12)
-                          + (st["asm_lambda_flops"] - f32l) / (FP64_PEAK_TFLOPS * 1e12))
+                          + (st["asm_lambda_flops"] - f32l) / (FP64_PEAK_TFLOPS * 1e12) + st["asm_predict_flops"] / (BF16_PEAK_TFLOPS * 1e12))
         res["roofline_step"] = {"bound": "mfma", "ideal_ms_per_step": ideal_ms / steps, "ms_per_step": 1e3 * dt / steps,
                                 "frac": ideal_ms / steps / (1e3 * dt / steps),
                                 "algorithmic_flops_per_step": {"gemm_f64": st["asm_gemm_flops"] / steps, "multiplier_f32": f32l / steps,
-                                                               "multiplier_f64": (st["asm_lambda_flops"] - f32l) / steps},
+                                                               "multiplier_f64": (st["asm_lambda_flops"] - f32l) / steps,
+                                                               "predictor_bf16": st["asm_predict_flops"] / steps},
                                 "note": "sum over the parts of (algorithmic flops / peak of that part's number type) over the measured step time; the "
                                         "f32 window GEMM is counted with the fp64 group (conservative: its flops are priced at the fp64 peak)",
                                 "hbm_bytes_per_step_all_kernels": (sum(v["per_step"] for v in traffic.values()) if traffic else None)}
         res["time_shares"] = {"multiplier_kernels_both_streams": st["asm_lambda_ms"] / st["total_ms"], "gemms": st["asm_gemm_ms"] / st["total_ms"],
-                              "set_bookkeeping_kernels": st["asm_update_ms"] / st["total_ms"]}
+                              "set_bookkeeping_kernels": st["asm_update_ms"] / st["total_ms"], "first_set_predictor": st["asm_predict_ms"] / st["total_ms"]}
         res["solver"]["checked_with_P_itself"] = int(st["asm_full_checks"])
         res["solver"]["inverse_check"] = {"max_abs_P_Pinv_minus_I": st["asm_e2max"], "max_abs_P_Kunc_plus_tq": st["asm_e1max"]}
         res["dtype"] = "f64"

@@ -79,7 +79,8 @@ typedef struct {
                                 (asm_tail_k, one workgroup per problem, no lock-step rounds): the chains of a task, a
                                 controller's single QP; 0 = 256 (the most the kernel's slabs hold), < 0 = never */
   int32_t asm_predict_iters; /* iterations of the dual accelerated-projected-gradient predictor that names the FIRST active sets of
-                                the rounds (bf16 MFMA, csrc/qp_predict.h): 0 = 24, < 0 = off (first sets = the bounds x_unc violates).
+                                the rounds (bf16 MFMA, csrc/qp_predict.h): 0 = adaptive (0.3 per bound x_unc violates, 8 .. 64, by workgroup of 64
+                                problems), > 0 = that many (<= 64), < 0 = off (first sets = the bounds x_unc violates).
                                 Affects only the number of rounds, never a result; used when n >= 512, nu <= 64, no caller's guess */
   float ipm_tol;             /* PDIP exit, objective scaled by 1/median(diag P):
                                 |r_d|_inf and mu <= tol*max(1,|q|_inf); 0 = 1e-2 */

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d, int nrows) {
     d.prec[p] = (d.use_f32 && !d.guess && !(d.pred_w && d.pred_f64)) ? 0 : 1;   // a caller's guess (a predicted set) is expected to be right: fp64 at once
     d.redo[p] = 0;
     d.ninf_best[p] = 0x7fffffff; d.alpha[p] = ASM_GRACE;
-    d.hi[p] = wi;
+    d.hi[p] = max(wi, d.guess ? 0 : d.pred_w);           // (a predicted set may hold bounds anywhere in the predictor's window)
   }
 }
 

@@ -44,26 +44,35 @@ typedef float pf32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 pbf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 pf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int PRED_NT = 4;                   // 16-column tiles per wave
 constexpr int PRED_NW = 8;                   // waves per workgroup
-constexpr int PRED_W = 16 * PRED_NT * PRED_NW;   // 512 columns
-constexpr int PRED_KS = PRED_W / 32;         // k-steps of v_mfma_f32_16x16x32_bf16
-constexpr int PRED_LDY = PRED_W + 8;         // bf16 per row of Y: 16 B of padding -> the 16 rows of a fragment read hit 64 distinct banks
 constexpr int PRED_MAXIT = 64;
+// Two instances: <NT = 4 column tiles per wave, PT = 4 problem tiles>: window 512, 64 problems per workgroup (the CDU batch: its
+// multipliers live in the first 480 columns); <8, 2>: window 1024, 32 problems per workgroup, for batches whose sets reach further
+// (larger state spreads: sx >= 3) -- four times the L2 traffic per problem (2 MB of H' for 32 problems), chosen per call from the
+// extent of the bounds x_unc violates (solve_segment_asm).
+template <int NT> struct PredCfg {
+  static constexpr int W = 16 * NT * PRED_NW;      // columns of the window
+  static constexpr int KS = W / 32;                // k-steps of v_mfma_f32_16x16x32_bf16
+  static constexpr int LDY = W + 8;                // bf16 per row of Y: 16 B of padding -> the 16 rows of a fragment read hit 64 distinct banks
+};
+constexpr int PRED_W = PredCfg<4>::W;        // the default window: 512 columns
+constexpr int PRED_W2 = PredCfg<8>::W;       // the wide one: 1024
 
 struct PredArgs {
-  const pu32x4* Hf;      // [NW waves][KS][NT][64] fragments of bf16(H'[0:W, 0:W]), H' = H diag(t), t_k = 1 / (L H_kk): lane (li, lq) of (w, ks, jt) holds H[16 (w NT + jt) + li][32 ks + 8 lq .. + 8]
-                         // (the NT fragments a wave needs for one k-step are 4 KB of consecutive memory: pred_frag_index)
-  int iters;
+  const pu32x4* Hf;      // [NW waves][KS][NT][64] fragments of bf16(H'[0:W, 0:W]), H' = H diag(t), t_k = 1 / (L H_kk): lane (li, lq) of (w, ks, jt) holds H'[16 (w NT + jt) + li][32 ks + 8 lq .. + 8]
+                         // (the NT fragments a wave needs for one k-step are NT KB of consecutive memory: pred_frag_index)
+  int iters;             // iterations; with `adaptive` the most a workgroup may take
+  int* itsum;            // device counter: += iterations after the first of every workgroup (statistics: the executed flops)
+  int adaptive;          // 1: every workgroup sets its own count from the bounds x_unc violates in its problems (see asm_predict_k)
   float beta[PRED_MAXIT];   // momentum of iteration k (beta[0] = 0)
 };
 
-__host__ __device__ constexpr int pred_lds_bytes(int nu) {
-  return 64 * PRED_LDY * 2 + 2 * 64 * (nu + 4) * 4 + 16;      // (nu a multiple of 4)
+template <int NT, int PT> __host__ __device__ constexpr int pred_lds_bytes(int nu) {
+  return 16 * PT * PredCfg<NT>::LDY * 2 + 2 * 16 * PT * (nu + 4) * 4 + 16;      // (nu a multiple of 4; the last 16 bytes: the violation count)
 }
 
-__host__ __device__ constexpr size_t pred_frag_index(int jtg, int ks, int lane) {   // 16-byte fragment of column tile jtg (0 .. W / 16), k-step ks
-  return (((size_t)(jtg / PRED_NT) * PRED_KS + ks) * PRED_NT + (jtg % PRED_NT)) * 64 + lane;
+template <int NT> __host__ __device__ constexpr size_t pred_frag_index(int jtg, int ks, int lane) {   // 16-byte fragment of column tile jtg (0 .. W / 16), k-step ks
+  return (((size_t)(jtg / NT) * PredCfg<NT>::KS + ks) * NT + (jtg % NT)) * 64 + lane;
 }
 
 __device__ __forceinline__ unsigned pred_bf16(float x) {          // round to nearest even, as a 16-bit pattern
@@ -71,31 +80,34 @@ __device__ __forceinline__ unsigned pred_bf16(float x) {          // round to ne
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+template <int NT, int PT>
 __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
-  constexpr int NT = PRED_NT, W = PRED_W, KS = PRED_KS, LDY = PRED_LDY;
-  unsigned short* Y = reinterpret_cast<unsigned short*>(sm_raw);              // [64][LDY] bf16 patterns
+  constexpr int KS = PredCfg<NT>::KS, LDY = PredCfg<NT>::LDY, MR = 16 * PT;
+  unsigned short* Y = reinterpret_cast<unsigned short*>(sm_raw);              // [MR][LDY] bf16 patterns
   const int ldb = d.nu + 4;                                                    // (rows 16 B aligned; 16 rows of a float4 read hit distinct banks for nu = 32)
-  float* lbs = reinterpret_cast<float*>(Y + 64 * LDY);                         // [64][nu + 4]
-  float* ubs = lbs + 64 * ldb;
+  float* lbs = reinterpret_cast<float*>(Y + MR * LDY);                         // [MR][nu + 4]
+  float* ubs = lbs + MR * ldb;
+  int* nviol = reinterpret_cast<int*>(ubs + MR * ldb);                         // bounds x_unc violates, summed over the workgroup's problems
   constexpr int NTH = 64 * PRED_NW;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int p0 = blockIdx.x * 64;
-  for (int i = tid; i < 64 * d.nu; i += NTH) {
+  const int p0 = blockIdx.x * MR;
+  for (int i = tid; i < MR * d.nu; i += NTH) {
     const int r = i / d.nu, k = i - r * d.nu;
     const size_t p = (size_t)min(p0 + r, d.nseg - 1);
     lbs[r * ldb + k] = (float)d.lb[p * d.nu + k];
     ubs[r * ldb + k] = (float)d.ub[p * d.nu + k];
   }
-  for (int i = tid; i < 64 * LDY / 2; i += NTH) reinterpret_cast<unsigned*>(Y)[i] = 0u;
+  for (int i = tid; i < MR * LDY / 2; i += NTH) reinterpret_cast<unsigned*>(Y)[i] = 0u;
+  if (tid == 0) *nviol = 0;
   // ---- state, in pairs of consecutive columns (packed f32 arithmetic, v_cvt_pk_bf16_f32): sx = x_unc as two f16, sm = mu as two bf16;
   // pair (jt, pt, h): problem 16 pt + li, columns 16 (w NT + jt) + 4 lq + 2 h, + 1
-  unsigned sx[NT][4][2], sm[NT][4][2];
+  unsigned sx[NT][PT][2], sm[NT][PT][2];
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < PT; ++pt) {
       const size_t p = (size_t)min(p0 + 16 * pt + li, d.nseg - 1);
       const double* xr = d.xunc + p * d.np + 16 * (w * NT + jt) + 4 * lq;
 #pragma unroll
@@ -121,13 +133,18 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
   auto hload = [&](int ksn, int jt) __attribute__((always_inline)) {
     return __builtin_bit_cast(pu32x4, __builtin_amdgcn_raw_buffer_load_b128(rH, l16 + jt * 1024, hw0 + ksn * (NT * 1024), 0));   // (jt KB: the immediate)
   };
-  for (int it = 0; it < a.iters; ++it) {
+  // Iterations: the harder the batch, the more it takes to name its sets (CDU plant, Hamming distance <= 3 from the converged set: 12
+  // iterations at 45 violated bounds per problem, 24 at 100, 40 at 140, 48 at 170, ~60 at 210) -- 0.3 per bound x_unc violates, by
+  // workgroup (its 64 problems come from one batch), between 8 and a.iters.  The count is the number of non-zeros after iteration 0:
+  // y = 0 there, so nu+ = x_unc - clip(x_unc, lb, ub).
+  int nit = a.iters;
+  for (int it = 0; it < nit; ++it) {
     // ---- x = x_unc - H y on the matrix pipes: acc[jt][pt][r] = sum_k H[col][k] y[problem][k]
-    pf32x4 acc[NT][4];
+    pf32x4 acc[NT][PT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) acc[jt][pt] = pf32x4{0.f, 0.f, 0.f, 0.f};
+      for (int pt = 0; pt < PT; ++pt) acc[jt][pt] = pf32x4{0.f, 0.f, 0.f, 0.f};
     // (all KS k-steps: the multipliers of the CDU batch reach column ~480 of 512 -- stopping at the last non-zero column of Y saved one
     // step in sixteen and cost a conditional per group of steps; iteration 0 has y = 0 and skips the phase)
 #ifdef PRED_NO_MFMA
@@ -149,13 +166,13 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
 #pragma unroll
           for (int jt = 0; jt < NT; ++jt) hb[(ks + RD - 1) % RD][jt] = hload(ks + RD - 1, jt);
         }
-        pu32x4 yf[4];
+        pu32x4 yf[PT];
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) yf[pt] = *reinterpret_cast<const pu32x4*>(Y + (16 * pt + li) * LDY + 32 * ks + 8 * lq);
+        for (int pt = 0; pt < PT; ++pt) yf[pt] = *reinterpret_cast<const pu32x4*>(Y + (16 * pt + li) * LDY + 32 * ks + 8 * lq);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-          for (int pt = 0; pt < 4; ++pt)
+          for (int pt = 0; pt < PT; ++pt)
             acc[jt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8, hb[b][jt]), __builtin_bit_cast(pbf16x8, yf[pt]),
                                                                   acc[jt][pt], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);                                       // (one k-step per scheduling region: bounded live ranges)
@@ -164,17 +181,18 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
     __syncthreads();                                                             // every wave is done reading Y
     // ---- prox step, momentum, Y rewritten in place (each lane owns its elements)
     const pf32x2 beta2 = {a.beta[it], a.beta[it]};
-    const bool last = it + 1 == a.iters;
+    const bool last = it + 1 == nit;
     // (per-lane bases of the LDS accesses below, hidden from the optimiser once per iteration: left alone it hoists ~50 loop-invariant
     // addresses out of the iteration loop and keeps them in scratch memory; from these bases every address is an immediate offset)
-    unsigned short* Yl = Y + li * LDY + 64 * w + 4 * lq;
+    unsigned short* Yl = Y + li * LDY + 16 * NT * w + 4 * lq;
     const float* lbl = lbs + li * ldb;
     const float* ubl = ubs + li * ldb;
     asm volatile("" : "+v"(Yl), "+v"(lbl), "+v"(ubl));
+    int nv0 = 0;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < PT; ++pt) {
       // (nu is a multiple of 4 and so is the lane's first column: its four columns are four consecutive inputs of one stage; when nu
-      // divides 32 the column tiles jt and jt + 2 see the same inputs: their bounds are read once)
+      // divides 32 the column tiles jt and jt + 2 see the same inputs: their bounds are read once -- NT is even)
       pf32x4 lb4[2], ub4[2];
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
@@ -205,6 +223,7 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
           const pf32x2 yn = beta2 * (nun - nu) + nun;
           yb[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(yn, pbf16x2));
           sm[jt][pt][h] = __builtin_bit_cast(unsigned, __builtin_convertvector(nun, pbf16x2));
+          if (it == 0) nv0 += ((sm[jt][pt][h] & 0x7fffu) != 0u) + ((sm[jt][pt][h] & 0x7fff0000u) != 0u);
           if (last) {                                                           // the predicted set: the sign of the multiplier
             // (nun itself, not its bf16 image; exact zeros come out of the projection)
             acc[jt][pt][2 * h] = nun[0]; acc[jt][pt][2 * h + 1] = nun[1];
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
       for (int jt = 0; jt < NT; ++jt) {
         const int c0 = 16 * (w * NT + jt) + 4 * lq;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
           const int p = p0 + 16 * pt + li;
           unsigned wd = 0;
 #pragma unroll
@@ -236,8 +255,36 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
         }
       }
     }
+    if (it == 0 && a.adaptive) {
+      for (int off = 32; off > 0; off >>= 1) nv0 += __shfl_xor(nv0, off);
+      if (lane == 0 && nv0) atomicAdd(nviol, nv0);
+    }
     __syncthreads();                                                             // Y of the next iteration is complete
+    if (it == 0 && a.adaptive) nit = min(a.iters, max(8, (3 * *nviol) / (10 * MR)));
+    if (it == 0 && tid == 0 && a.itsum) atomicAdd(a.itsum, nit - 1);
   }
+}
+
+// How far along the horizon do the bounds x_unc violates reach?  *cnt += problems with a violated bound in the columns [c0, c1).
+// One wave per problem, sixteen problems per wave (one atomic per workgroup).
+__global__ __launch_bounds__(256) void asm_extent_k(AsmDev d, int c0, int c1, int* cnt) {
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int hit = 0;
+  for (int q = 0; q < 16; ++q) {
+    const int p = blockIdx.x * 64 + wave * 16 + q;
+    if (p >= d.nseg) break;
+    int v = 0;
+    for (int r = c0 + lane; r < c1; r += 64) {
+      const int k = r % d.nu;
+      const double x = d.xunc[(size_t)p * d.np + r];
+      v |= x > d.ub[(size_t)p * d.nu + k] || x < d.lb[(size_t)p * d.nu + k];
+    }
+    hit += __any(v) ? 1 : 0;
+  }
+  if (lane == 0) wsum[wave] = hit;
+  __syncthreads();
+  if (threadIdx.x == 0) { const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3]; if (t) atomicAdd(cnt, t); }
 }
 
 }  // namespace nnmpc

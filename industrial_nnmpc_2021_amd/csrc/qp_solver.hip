@@ -712,8 +712,9 @@ struct nnmpc_qp {
   double p_inf = 0.0;       // max row sum of |P|
   double *asm_tnorm = nullptr, *asm_tslack = nullptr;
   // first-set predictor (qp_predict.h): bf16 fragments of Pinv[0:512, 0:512], step sizes; set by nnmpc_qp_set_inverse when the problem is large enough
-  pu32x4* pred_Hf = nullptr;
-  double pred_L = 0.0;          // lambda_max(D^-1/2 Pinv_WW D^-1/2)
+  struct PredWin { pu32x4* Hf = nullptr; double L = 0.0; int W = 0; };   // L = 1.05 lambda_max(D^-1/2 Pinv_WW D^-1/2); 0: window not available
+  PredWin pred[2];              // [0]: 512 columns, 64 problems per workgroup; [1]: 1024 columns, 32 per workgroup (sets that reach further)
+  int* pred_cnt = nullptr;      // device counters: [0] asm_extent_k, [1] sum of the workgroups' iterations after the first (asm_predict_k)
   double* asm_work;
   int seg_max;          // problems per segment (q / warm start precomputed per segment)
   double* x0_64;        // [seg_max][ka]
@@ -730,7 +731,7 @@ struct nnmpc_qp {
   // pinned host copies of the active-set pass's read-backs (the round counters, the status of a segment): into pageable memory a
   // "hipMemcpyAsync" is staged and waited for inside the runtime (a blocking wait); pinned, the copy is a packet on the stream and
   // stream_sync polls for it.
-  int* pin_cnt = nullptr;            // [ASM_NCNT]
+  int* pin_cnt = nullptr;            // [ASM_NCNT + 4]: the round counters, then the predictor's iteration sum
   int* pin_st = nullptr;             // [seg_max]
   bool profiling;
   bool gemm_error = false;      // a GEMM was asked for in a form no kernel implements (gemm64): the call in progress fails
@@ -971,6 +972,56 @@ int solve_segment(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb
   return 0;
 }
 
+
+// One window of the first-set predictor (qp_predict.h): bf16 MFMA fragments of H' = Pinv[0:W, 0:W] diag(t), t_k = 1 / (L Pinv_kk),
+// L = lambda_max(D^-1/2 Pinv_WW D^-1/2) (power iteration, 5 % margin: a step that is a little short costs nothing but speed).
+// hh: the padded inverse (np x np, host).  Leaves pw.L = 0 when the window does not apply.
+template <int NT>
+int build_predictor(nnmpc_qp* h, const std::vector<double>& hh, int np, nnmpc_qp::PredWin& pw) {
+  constexpr int W = PredCfg<NT>::W, KS = PredCfg<NT>::KS;
+  pw.L = 0.0; pw.W = W;
+  std::vector<double> dg(W);
+  for (int j = 0; j < W; ++j) { dg[j] = hh[(size_t)j * np + j]; if (!(dg[j] > 0.0)) return 0; }
+  std::vector<double> v(W, 1.0), u(W), isd(W);
+  for (int j = 0; j < W; ++j) isd[j] = 1.0 / std::sqrt(dg[j]);
+  double lam = 0.0;
+  for (int itp = 0; itp < 200; ++itp) {
+    double nv = 0.0;
+    for (int i = 0; i < W; ++i) nv += v[i] * v[i];
+    nv = std::sqrt(nv);
+    for (int i = 0; i < W; ++i) v[i] *= isd[i] / nv;
+    for (int i = 0; i < W; ++i) {
+      double sacc = 0.0;
+      const double* hr = &hh[(size_t)i * np];
+      for (int j = 0; j < W; ++j) sacc += hr[j] * v[j];
+      u[i] = sacc * isd[i];
+    }
+    double num = 0.0;
+    for (int i = 0; i < W; ++i) num += u[i] * v[i] / isd[i];
+    const bool conv = std::fabs(num - lam) <= 1e-6 * std::fabs(num);
+    lam = num;
+    v = u;
+    if (conv && itp > 8) break;
+  }
+  if (!(lam > 0.0)) return 0;
+  const double L = 1.05 * lam;
+  std::vector<unsigned short> hf((size_t)W * W);
+  auto bf = [](double x) { float f = (float)x; unsigned u32; memcpy(&u32, &f, 4); return (unsigned short)((u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16); };
+  for (int jt = 0; jt < W / 16; ++jt)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int li = lane & 15, lq = lane >> 4;
+        for (int e = 0; e < 8; ++e) {
+          const int k = 32 * ks + 8 * lq + e;
+          hf[pred_frag_index<NT>(jt, ks, lane) * 8 + e] = bf(hh[(size_t)(16 * jt + li) * np + k] / (L * dg[k]));   // H' = H diag(t)
+        }
+      }
+  if (!pw.Hf) { int rc = dev_alloc(h, (unsigned short**)&pw.Hf, hf.size()); if (rc) return rc; }
+  HIPCHK(hipMemcpy(pw.Hf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+  pw.L = L;
+  return 0;
+}
+
 // Shared-inverse active-set pass over one segment; problems it cannot finish are marked 3 in
 // h->asm_status and re-solved by the PDIP path (solve_segment) on a compacted copy.
 int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double* lb_dev, const double* ub_dev,
@@ -1027,19 +1078,51 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   // first sets: named by the dual projected-gradient predictor inside its window (qp_predict.h), by the bounds x_unc violates beyond
   // it (and everywhere when the predictor is off, the problem small, or the caller brought a guess)
   a.pred_w = 0; a.pred_f64 = 0;
+  double pred_flops_per_it = 0.0;
   {
     static const int env_it = getenv("NNMPC_PRED_ITERS") ? atoi(getenv("NNMPC_PRED_ITERS")) : -1;   // (the variable: diagnostics, A/B; 0 = off)
-    const int iters = env_it >= 0 ? std::min(env_it, (int)PRED_MAXIT) : h->opts.asm_predict_iters;
-    if (iters > 0 && h->pred_L > 0.0 && !guess_dev && !small && !tail_only && Wx >= PRED_W) {
+    // (opts.asm_predict_iters: 0 adaptive, > 0 that many, < 0 off; the variable: 0 off, > 0 that many)
+    const int iters_req = env_it >= 0 ? (env_it == 0 ? -1 : std::min(env_it, (int)PRED_MAXIT)) : h->opts.asm_predict_iters;
+    const int iters = iters_req == 0 ? (int)PRED_MAXIT : iters_req;
+    if (iters > 0 && h->pred[0].L > 0.0 && !guess_dev && !small && !tail_only && Wx >= PRED_W) {
       PredArgs pa;
-      pa.Hf = h->pred_Hf; pa.iters = iters;
+      pa.iters = iters; pa.adaptive = iters_req == 0; pa.itsum = h->profiling ? h->pred_cnt + 1 : nullptr;
+      if (h->profiling) HIPCHK(hipMemsetAsync(h->pred_cnt + 1, 0, 4, s));
       double t = 1.0;
       for (int k = 0; k < iters; ++k) { const double tn = 0.5 * (1.0 + std::sqrt(1.0 + 4.0 * t * t)); pa.beta[k] = (float)((t - 1.0) / tn); t = tn; }
       for (int k = iters; k < PRED_MAXIT; ++k) pa.beta[k] = 0.f;
-      // (flops: an upper bound -- the K loop of an iteration stops at the last column of Y in use)
-      EvScope es(h, 10, 2.0 * PRED_W * (double)PRED_W * (double)(iters - 1) * (double)(((nprob + 63) / 64) * 64));
-      hipLaunchKernelGGL(asm_predict_k, dim3((nprob + 63) / 64), dim3(64 * PRED_NW), pred_lds_bytes(h->nu), s, a, pa);
-      a.pred_w = PRED_W;
+      // Which window: the optimum's active bounds reach further along the horizon than the bounds x_unc violates.  When more than a
+      // quarter of the problems already violate a bound in the last quarter of the 512-column window (CDU plant: 0.05 % at sx = 2,
+      // 8 % at sx = 4, 46 % at sx = 6), the 1024-column instance names the sets -- four times the L2 traffic per problem and x_unc
+      // for those columns: 100 000 problems at sx = 6 (291 bounds each, the last one at column 757): 461 -> 412 ms per step; at
+      // sx = 4 (216 bounds, last column 629) it costs more than it saves (76 -> 88 ms).  (One 4-byte read-back; only handles that
+      // have the wide window pay it.)
+      int wide = 0;
+      static const int force_w = getenv("NNMPC_PRED_WIDE") ? atoi(getenv("NNMPC_PRED_WIDE")) : -1;   // (the variable: diagnostics, A/B; 0 / 1 forces the choice)
+      if (h->pred[1].L > 0.0 && lazy) {
+        if (force_w >= 0) wide = force_w;
+        else {
+          HIPCHK(hipMemsetAsync(h->pred_cnt, 0, 4, s));
+          hipLaunchKernelGGL(asm_extent_k, dim3((nprob + 63) / 64), dim3(256), 0, s, a, PRED_W - PRED_W / 4, PRED_W, h->pred_cnt);
+          HIPCHK(hipMemcpyAsync(h->pin_cnt, h->pred_cnt, 4, hipMemcpyDeviceToHost, s));
+          HIPCHK(stream_sync(s));
+          wide = h->pin_cnt[0] * 4 > nprob;
+          h->pin_cnt[0] = 0;
+        }
+      }
+      if (wide && Wx < PRED_W2) {
+        EvScope es(h, 5, 2.0 * (PRED_W2 - Wx) * (double)h->ka * nprob);
+        gemm64(h, h->asm_xunc + Wx, h->np, h->x0_64, h->ka, h->Kunc64 + (size_t)Wx * h->ka, h->ka, segp, PRED_W2 - Wx, h->ka);
+        Wx = PRED_W2; a.Wx = Wx;
+      }
+      const int W = wide ? PRED_W2 : PRED_W, MR = wide ? 32 : 64;
+      pa.Hf = h->pred[wide].Hf;
+      // (flops: the dense count -- every k-step of every iteration after the first; the iterations are summed on the device)
+      pred_flops_per_it = 2.0 * W * (double)W * MR;
+      EvScope es(h, 10, 0.0);
+      if (wide) hipLaunchKernelGGL((asm_predict_k<8, 2>), dim3((nprob + 31) / 32), dim3(64 * PRED_NW), (pred_lds_bytes<8, 2>(h->nu)), s, a, pa);
+      else hipLaunchKernelGGL((asm_predict_k<4, 4>), dim3((nprob + 63) / 64), dim3(64 * PRED_NW), (pred_lds_bytes<4, 4>(h->nu)), s, a, pa);
+      a.pred_w = W;
       { static const int pf = getenv("NNMPC_PRED_F64") ? atoi(getenv("NNMPC_PRED_F64")) : 0; a.pred_f64 = pf; }   // (the variable: diagnostics, A/B)
     }
   }
@@ -1329,9 +1412,12 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   hipLaunchKernelGGL(asm_certify_k, dim3(nprob), dim3(256), 0, s, a, h->pscale);
   int* st = h->pin_st;
   HIPCHK(hipMemcpyAsync(st, h->asm_status, (size_t)nprob * sizeof(int), hipMemcpyDeviceToHost, s));
+  int* pin_its = h->pin_cnt + ASM_NCNT;
+  if (h->profiling && pred_flops_per_it > 0.0) HIPCHK(hipMemcpyAsync(pin_its, h->pred_cnt + 1, 4, hipMemcpyDeviceToHost, s));
   if (defer_cnt) HIPCHK(hipMemcpyAsync(cnt, h->asm_counters, ASM_NCNT * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(stream_sync(s));
   if (defer_cnt) h->stats.asm_full_checks += cnt[ASM_CNT_DONE];
+  if (h->profiling && pred_flops_per_it > 0.0) h->stats.asm_predict_flops += pred_flops_per_it * (double)*pin_its;
   HIPCHK(hipGetLastError());
   std::vector<int> fb;
   int ninvalid = 0;
@@ -1426,8 +1512,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   // problems of the reference's regime settle within 40 iterations and never see the difference)
   h->asm_tail_budget = o.asm_max_rounds <= 0 ? 50000 : o.asm_max_rounds;
   if (o.asm_max_rounds <= 0) o.asm_max_rounds = 200;
-  if (o.asm_predict_iters == 0) o.asm_predict_iters = 24;
-  if (o.asm_predict_iters > PRED_MAXIT) o.asm_predict_iters = PRED_MAXIT;
+  if (o.asm_predict_iters > PRED_MAXIT) o.asm_predict_iters = PRED_MAXIT;   // (0: adaptive, 8 .. PRED_MAXIT by workgroup)
   if (o.sub_steps < 2) o.sub_steps = 2;
   if (o.ipm_tol <= 0.f) o.ipm_tol = 1e-2f;
   if (o.refine_tol <= 0.0) o.refine_tol = 1e-10;
@@ -1502,7 +1587,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->q64_all, G * np); A_(h->uunc_all, G * np);
   A_(h->lb_d, G * nu); A_(h->ub_d, G * nu);
   A_(h->in_stage, G * n_aug);
-  if (!rc && hipHostMalloc((void**)&h->pin_cnt, ASM_NCNT * sizeof(int)) != hipSuccess) { set_error("nnmpc_qp_create: hipHostMalloc failed"); rc = NNMPC_EHIP; }
+  if (!rc && hipHostMalloc((void**)&h->pin_cnt, (ASM_NCNT + 4) * sizeof(int)) != hipSuccess) { set_error("nnmpc_qp_create: hipHostMalloc failed"); rc = NNMPC_EHIP; }
   if (!rc && hipHostMalloc((void**)&h->pin_st, G * sizeof(int)) != hipSuccess) { set_error("nnmpc_qp_create: hipHostMalloc failed"); rc = NNMPC_EHIP; }
   A_(d.lb64, (size_t)S * nu); A_(d.ub64, (size_t)S * nu);
   A_(d.slot_prob, S); A_(d.age, S); A_(d.next_prob, 1);
@@ -1625,53 +1710,19 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
     HIPCHK(hipMemcpy(h->H32, h32.data(), h32.size() * 4, hipMemcpyHostToDevice));
   }
   HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
-  // ---- first-set predictor (qp_predict.h): bf16 MFMA fragments of the leading PRED_W x PRED_W block, scaled by the diagonal step sizes
-  // t_k = 1 / (L Pinv_kk) (H' = H diag(t)) with L = lambda_max(D^-1/2 Pinv_WW D^-1/2) (power iteration, 5 % margin: a step that is a little short
-  // costs nothing but speed)
-  h->pred_L = 0.0;
-  if (np >= PRED_W && n >= PRED_W && h->nu <= 64 && h->nu % 4 == 0 && h->opts.asm_predict_iters > 0) {
-    const int W = PRED_W;
-    std::vector<double> dg(W);
-    bool okd = true;
-    for (int j = 0; j < W; ++j) { dg[j] = hh[(size_t)j * np + j]; okd = okd && dg[j] > 0.0; }
-    if (okd) {
-      std::vector<double> v(W, 1.0), u(W);
-      double lam = 0.0;
-      for (int itp = 0; itp < 200; ++itp) {
-        double nv = 0.0;
-        for (int i = 0; i < W; ++i) nv += v[i] * v[i];
-        nv = std::sqrt(nv);
-        for (int i = 0; i < W; ++i) v[i] /= nv;
-        for (int i = 0; i < W; ++i) {
-          double sacc = 0.0;
-          const double* hr = &hh[(size_t)i * np];
-          for (int j = 0; j < W; ++j) sacc += hr[j] * v[j] / std::sqrt(dg[j]);
-          u[i] = sacc / std::sqrt(dg[i]);
-        }
-        double num = 0.0;
-        for (int i = 0; i < W; ++i) num += u[i] * v[i];
-        const bool conv = std::fabs(num - lam) <= 1e-6 * std::fabs(num);
-        lam = num;
-        v = u;
-        if (conv && itp > 8) break;
-      }
-      if (lam > 0.0 && lam == lam) {
-        h->pred_L = 1.05 * lam;
-        std::vector<double> tcol(W);
-        for (int j = 0; j < W; ++j) tcol[j] = 1.0 / (h->pred_L * dg[j]);
-        std::vector<unsigned short> hf((size_t)W * W);
-        auto bf = [](double x) { float f = (float)x; unsigned u32; memcpy(&u32, &f, 4); return (unsigned short)((u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16); };
-        for (int jt = 0; jt < W / 16; ++jt)
-          for (int ks = 0; ks < PRED_KS; ++ks)
-            for (int lane = 0; lane < 64; ++lane) {
-              const int li = lane & 15, lq = lane >> 4;
-              for (int e = 0; e < 8; ++e)
-                hf[pred_frag_index(jt, ks, lane) * 8 + e] = bf(hh[(size_t)(16 * jt + li) * np + 32 * ks + 8 * lq + e] * tcol[32 * ks + 8 * lq + e]);   // H' = H diag(t)
-            }
-        if (!h->pred_Hf) { int rc = dev_alloc(h, (unsigned short**)&h->pred_Hf, hf.size()); if (rc) return rc; }
-        HIPCHK(hipMemcpy(h->pred_Hf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes(h->nu)));
-      }
+  // ---- first-set predictor (qp_predict.h): the 512-column window, and the 1024-column one for batches whose sets reach further
+  h->pred[0].L = h->pred[1].L = 0.0;
+  if (h->nu <= 64 && h->nu % 4 == 0 && h->opts.asm_predict_iters >= 0) {
+    if (np >= PRED_W && n >= PRED_W) {
+      const int rc = build_predictor<4>(h, hh, np, h->pred[0]);
+      if (rc) return rc;
+      if (!h->pred_cnt) { const int rc2 = dev_alloc(h, &h->pred_cnt, 4); if (rc2) return rc2; }
+      HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes<4, 4>(h->nu)));
+    }
+    if (np >= PRED_W2 && n >= PRED_W2 && h->pred[0].L > 0.0) {
+      const int rc = build_predictor<8>(h, hh, np, h->pred[1]);
+      if (rc) return rc;
+      HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes<8, 2>(h->nu)));
     }
   }
   // ---- verify the inverse once, on the device copies the solves will use:

@@ -9,6 +9,10 @@
 #include <cstring>
 #include <vector>
 #include <random>
+#ifndef PRED_MICRO_NT
+#define PRED_MICRO_NT 4
+#define PRED_MICRO_PT 4
+#endif
 #include "qp_predict.h"
 using namespace nnmpc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -16,7 +20,8 @@ static unsigned short bfh(float f) { unsigned u; memcpy(&u, &f, 4); return (unsi
 static float bff(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
 int main(int argc, char** argv) {
   const int nseg = argc > 1 ? atoi(argv[1]) : 16384, iters = argc > 2 ? atoi(argv[2]) : 24, nu = argc > 3 ? atoi(argv[3]) : 32;
-  const int W = PRED_W, n = 1024, np = 1024;
+  constexpr int NTm = PRED_MICRO_NT, PTm = PRED_MICRO_PT;
+  const int W = PredCfg<NTm>::W, n = 2048, np = 2048;
   std::mt19937_64 rng(3);
   std::normal_distribution<double> g(0.0, 1.0);
   std::vector<double> G((size_t)W * W), H((size_t)W * W);
@@ -41,10 +46,10 @@ int main(int argc, char** argv) {
   std::vector<unsigned short> hf((size_t)W * W), hb((size_t)W * W);
   for (int j = 0; j < W; ++j) for (int k = 0; k < W; ++k) hb[(size_t)j * W + k] = bfh((float)(H[(size_t)j * W + k] * (1.0 / (L * H[(size_t)k * W + k]))));   // H' = H diag(t)
   for (int jt = 0; jt < W / 16; ++jt)
-    for (int ks = 0; ks < PRED_KS; ++ks)
+    for (int ks = 0; ks < PredCfg<NTm>::KS; ++ks)
       for (int lane = 0; lane < 64; ++lane)
         for (int e = 0; e < 8; ++e)
-          hf[pred_frag_index(jt, ks, lane) * 8 + e] = hb[(size_t)(16 * jt + (lane & 15)) * W + 32 * ks + 8 * (lane >> 4) + e];
+          hf[pred_frag_index<NTm>(jt, ks, lane) * 8 + e] = hb[(size_t)(16 * jt + (lane & 15)) * W + 32 * ks + 8 * (lane >> 4) + e];
   std::vector<double> xunc((size_t)nseg * np), lb((size_t)nseg * nu), ub((size_t)nseg * nu);
   for (auto& x : xunc) x = 0.8 * g(rng);
   for (int p = 0; p < nseg; ++p) for (int k = 0; k < nu; ++k) { lb[(size_t)p * nu + k] = -1.0 - 0.3 * fabs(g(rng)); ub[(size_t)p * nu + k] = 1.0 + 0.3 * fabs(g(rng)); }
@@ -57,14 +62,14 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dst, (size_t)nseg * n)); CK(hipMemset(dst, 0, (size_t)nseg * n));
   CK(hipMalloc(&dHf, hf.size() * 2)); CK(hipMemcpy(dHf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
   d.xunc = dx; d.lb = dlb; d.ub = dub; d.st = dst;
-  PredArgs pa; pa.Hf = dHf; pa.iters = iters;
+  PredArgs pa; pa.Hf = dHf; pa.iters = iters; pa.adaptive = 0; pa.itsum = nullptr;
   { double t = 1.0; for (int k = 0; k < PRED_MAXIT; ++k) { const double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t)); pa.beta[k] = k < iters ? (float)((t - 1.0) / tn) : 0.f; t = tn; } }
-  CK(hipFuncSetAttribute((const void*)asm_predict_k, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes(nu)));
+  CK(hipFuncSetAttribute((const void*)asm_predict_k<NTm, PTm>, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes<NTm, PTm>(nu)));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(asm_predict_k, dim3((nseg + 63) / 64), dim3(64 * PRED_NW), pred_lds_bytes(nu), 0, d, pa);
+    hipLaunchKernelGGL((asm_predict_k<NTm, PTm>), dim3((nseg + 16 * PTm - 1) / (16 * PTm)), dim3(64 * PRED_NW), (pred_lds_bytes<NTm, PTm>(nu)), 0, d, pa);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep) best = std::min(best, ms);
   }
@@ -91,9 +96,9 @@ int main(int argc, char** argv) {
       }
     }
   }
-  const double flops = 2.0 * W * W * (double)(iters - 1) * (double)(((nseg + 63) / 64) * 64);
+  const double flops = 2.0 * W * W * (double)(iters - 1) * (double)nseg;
   printf("predict: %d problems, %d iterations, nu %d: %.3f ms (%.1f us per iteration and 64 problems per CU-slot; dense-count %.0f TFLOP/s bf16); "
          "emulation: %ld of %ld bound states differ (%.4f %%), %.1f active per problem\n", nseg, iters, nu, best,
-         1e3 * best / iters / std::max(1.0, ceil(nseg / 64.0 / 256.0)), flops / (best * 1e-3) / 1e12, diff, tot, 100.0 * diff / std::max(1L, tot), (double)act / ncheck);
+         1e3 * best / iters / std::max(1.0, ceil(nseg / (16.0 * PTm) / 256.0)), flops / (best * 1e-3) / 1e12, diff, tot, 100.0 * diff / std::max(1L, tot), (double)act / ncheck);
   return 0;
 }
