@@ -80,7 +80,9 @@ __device__ __forceinline__ unsigned pred_bf16(float x) {          // round to ne
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <int NT, int PT>
+// NU4: nu is a multiple of 4 -- a lane's four consecutive columns are four consecutive inputs of one stage, their bounds one 16-byte
+// read; else (nu >= 4, e.g. the CSTRs plant's 6 inputs) every column looks its bounds up by itself.
+template <int NT, int PT, bool NU4 = true>
 __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
   constexpr int KS = PredCfg<NT>::KS, LDY = PredCfg<NT>::LDY, MR = 16 * PT;
@@ -196,9 +198,18 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
       pf32x4 lb4[2], ub4[2];
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
-        if (jt < 2 || !per32) {
-          lb4[jt & 1] = *reinterpret_cast<const pf32x4*>(lbl + 16 * pt * ldb + kc0[jt]);
-          ub4[jt & 1] = *reinterpret_cast<const pf32x4*>(ubl + 16 * pt * ldb + kc0[jt]);
+        if constexpr (NU4) {
+          if (jt < 2 || !per32) {
+            lb4[jt & 1] = *reinterpret_cast<const pf32x4*>(lbl + 16 * pt * ldb + kc0[jt]);
+            ub4[jt & 1] = *reinterpret_cast<const pf32x4*>(ubl + 16 * pt * ldb + kc0[jt]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = kc0[jt] + r, kk = k >= d.nu ? k - d.nu : k;         // (nu >= 4: one wrap at most)
+            lb4[jt & 1][r] = lbl[16 * pt * ldb + kk];
+            ub4[jt & 1][r] = ubl[16 * pt * ldb + kk];
+          }
         }
         unsigned short* yp = Yl + 16 * pt * LDY + 16 * jt;
         const pu32x2 yw = *reinterpret_cast<const pu32x2*>(yp);

@@ -812,7 +812,7 @@ void ev_collect(nnmpc_qp* h) {
     else if (r.kind == 7) { h->stats.asm_lambda32_ms += ms; h->stats.asm_lambda32_launches += 1; }
     else if (r.kind == 8) { h->stats.asm_lambda64_ms += ms; h->stats.asm_lambda64_launches += 1; }
     else if (r.kind == 9) h->stats.asm_side_ms += ms;
-    else if (r.kind == 10) { h->stats.asm_predict_ms += ms; h->stats.asm_predict_launches += 1; h->stats.asm_predict_flops += r.flops; }
+    else if (r.kind == 10) { h->stats.asm_predict_ms += ms; h->stats.asm_predict_flops += r.flops; }   // (launches: counted at the launch, profiling or not)
   }
   h->ev_recs.clear();
   h->ev_used = 0;
@@ -1084,6 +1084,9 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     // (opts.asm_predict_iters: 0 adaptive, > 0 that many, < 0 off; the variable: 0 off, > 0 that many)
     const int iters_req = env_it >= 0 ? (env_it == 0 ? -1 : std::min(env_it, (int)PRED_MAXIT)) : h->opts.asm_predict_iters;
     const int iters = iters_req == 0 ? (int)PRED_MAXIT : iters_req;
+    // (not for the one-wave-per-problem path of small problems: measured on the CSTRs-size batch of 10 000 -- n = 540, nu = 6, cond 4e7 --
+    // the prediction takes the mean iteration count from 5.5 to 2, but a launch of asm_small_k lasts as long as its SLOWEST problem, and
+    // that one keeps its ~25 iterations: 1.76 ms per step without, 1.94 with the predictor)
     if (iters > 0 && h->pred[0].L > 0.0 && !guess_dev && !small && !tail_only && Wx >= PRED_W) {
       PredArgs pa;
       pa.iters = iters; pa.adaptive = iters_req == 0; pa.itsum = h->profiling ? h->pred_cnt + 1 : nullptr;
@@ -1115,13 +1118,16 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
         gemm64(h, h->asm_xunc + Wx, h->np, h->x0_64, h->ka, h->Kunc64 + (size_t)Wx * h->ka, h->ka, segp, PRED_W2 - Wx, h->ka);
         Wx = PRED_W2; a.Wx = Wx;
       }
-      const int W = wide ? PRED_W2 : PRED_W, MR = wide ? 32 : 64;
+      const bool nu4 = h->nu % 4 == 0;
+      const int W = wide ? PRED_W2 : PRED_W, MR = (wide || !nu4) ? 32 : 64;
       pa.Hf = h->pred[wide].Hf;
       // (flops: the dense count -- every k-step of every iteration after the first; the iterations are summed on the device)
       pred_flops_per_it = 2.0 * W * (double)W * MR;
+      h->stats.asm_predict_launches += 1;
       EvScope es(h, 10, 0.0);
       if (wide) hipLaunchKernelGGL((asm_predict_k<8, 2>), dim3((nprob + 31) / 32), dim3(64 * PRED_NW), (pred_lds_bytes<8, 2>(h->nu)), s, a, pa);
-      else hipLaunchKernelGGL((asm_predict_k<4, 4>), dim3((nprob + 63) / 64), dim3(64 * PRED_NW), (pred_lds_bytes<4, 4>(h->nu)), s, a, pa);
+      else if (nu4) hipLaunchKernelGGL((asm_predict_k<4, 4>), dim3((nprob + 63) / 64), dim3(64 * PRED_NW), (pred_lds_bytes<4, 4>(h->nu)), s, a, pa);
+      else hipLaunchKernelGGL((asm_predict_k<4, 2, false>), dim3((nprob + 31) / 32), dim3(64 * PRED_NW), (pred_lds_bytes<4, 2>(h->nu)), s, a, pa);
       a.pred_w = W;
       { static const int pf = getenv("NNMPC_PRED_F64") ? atoi(getenv("NNMPC_PRED_F64")) : 0; a.pred_f64 = pf; }   // (the variable: diagnostics, A/B)
     }
@@ -1712,14 +1718,15 @@ int nnmpc_qp_set_inverse(nnmpc_qp* h, const double* Hinv, const double* Kunc) {
   HIPCHK(hipMemcpy(h->Kunc64, kk.data(), kk.size() * 8, hipMemcpyHostToDevice));
   // ---- first-set predictor (qp_predict.h): the 512-column window, and the 1024-column one for batches whose sets reach further
   h->pred[0].L = h->pred[1].L = 0.0;
-  if (h->nu <= 64 && h->nu % 4 == 0 && h->opts.asm_predict_iters >= 0) {
+  if (h->nu <= 64 && h->nu >= 4 && h->opts.asm_predict_iters >= 0) {
     if (np >= PRED_W && n >= PRED_W) {
       const int rc = build_predictor<4>(h, hh, np, h->pred[0]);
       if (rc) return rc;
       if (!h->pred_cnt) { const int rc2 = dev_alloc(h, &h->pred_cnt, 4); if (rc2) return rc2; }
       HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes<4, 4>(h->nu)));
+      HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k<4, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes<4, 2>(h->nu)));
     }
-    if (np >= PRED_W2 && n >= PRED_W2 && h->pred[0].L > 0.0) {
+    if (np >= PRED_W2 && n >= PRED_W2 && h->pred[0].L > 0.0 && h->nu % 4 == 0) {
       const int rc = build_predictor<8>(h, hh, np, h->pred[1]);
       if (rc) return rc;
       HIPCHK(hipFuncSetAttribute((const void*)asm_predict_k<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes<8, 2>(h->nu)));
