@@ -716,7 +716,7 @@ def bench_qp(ctx, workload, B, steps, warmup, sx, method="auto", slots=0, seed0=
         if st["asm_predict_ms"] > 0:
             # first-set predictor (qp_predict.h): bf16 MFMA, f32 accumulate; flops = the dense count 2 W^2 per problem and iteration
             pach = st["asm_predict_flops"] / (st["asm_predict_ms"] * 1e-3) / 1e12
-            trp, trp_step, _ = _traffic_of(traffic, ["asm_predict_k"])
+            trp, trp_step, _ = _traffic_of(traffic, ["asm_predict_k<4, 4, true>", "asm_predict_k<8, 2, true>", "asm_predict_k<4, 2, false>"])
             pred = {"kernel": "asm_predict_k: dual accelerated projected gradient on the window (x = x_unc - H' y on v_mfma_f32_16x16x32_bf16, prox + momentum "
                               "elementwise), 64 problems per workgroup for all iterations, H' (512 KB bf16) streamed from L2 once per iteration",
                     "dtype": "bf16", "bound": "mfma", "achieved": pach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pach / BF16_PEAK_TFLOPS,

@@ -716,6 +716,9 @@ template <class T> __host__ __device__ constexpr int asm_nlt(int mb) { return as
 template <class T> __host__ __device__ constexpr int asm_rw(int mb) { return 2 * ASM_TS + 2 * mb * 16 + asm_nlt<T>(mb) * 256; }
 
 __host__ __device__ constexpr int asm_tix(int I, int J) { return I * (I + 1) / 2 + J; }
+// linear index t over the pairs (J, I), 0 <= J <= I < n, J-major (t = 0: (0, 0)): the J / the I of pair t
+__host__ __device__ constexpr int asm_tri_row(int n, int t) { int J = 0; while (t >= n - J) { t -= n - J; ++J; } return J; }
+__host__ __device__ constexpr int asm_tri_col(int n, int t) { int J = 0; while (t >= n - J) { t -= n - J; ++J; } return J + t; }
 template <int V> struct asm_ic { static constexpr int value = V; };
 template <int B, int E, class F>
 __device__ __forceinline__ void asm_sfor(F&& f) {          // f(asm_ic<B>{}), ..., f(asm_ic<E-1>{}): indices are constants
@@ -948,6 +951,29 @@ __device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* i
       for (int r = 0; r < 4; ++r) dt[li * 17 + N::kr(lq, r)] = -C[asm_tix(K + 1, K + 1)][r];
       ASM_FENCE();
       __builtin_amdgcn_sched_barrier(0);
+#ifdef ASM_REG_ILV
+      // ... then its factorisation INTERLEAVED with the rest of the trailing update: pivot step cc of the chain and the cc-th
+      // sixteenth of the remaining tiles share a scheduling region (the MFMAs fill the chain's dependency stalls -- with one wave
+      // per SIMD, the fp64 instance, nothing else does)
+      {
+        constexpr int NR = (MB - K - 1) * (MB - K) / 2 - 1;  // tiles of the trailing update besides (K + 1, K + 1)
+        T x[16];
+        asm_diag16_begin<T>(x, dt, idt, lane);
+        asm_sfor<0, 16>([&](auto cc) __attribute__((always_inline)) {
+          constexpr int c = decltype(cc)::value;
+          asm_diag16_step<T, c>(x);
+          asm_sfor<c * NR / 16, (c + 1) * NR / 16>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value + 1;       // linear index in the trailing block (0 = its first tile, done above)
+            constexpr int J = asm_tri_row(MB - K - 1, t), I = asm_tri_col(MB - K - 1, t);
+            trail(Kc, asm_ic<K + 1 + J>{}, asm_ic<K + 1 + I>{}, P);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        ASM_STAMP(6 + 3 * K);
+        bad |= asm_diag16_end<T>(x, Yt, lane);
+        ASM_FENCE();
+      }
+#else
       // ... then its factorisation together with the rest of the trailing update
       asm_sfor<K + 1, MB>([&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
@@ -959,6 +985,7 @@ __device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* i
       ASM_STAMP(6 + 3 * K);                                // (trailing update issued)
       bad |= asm_diag16<T>(dt, Yt, lane, idt);
       ASM_FENCE();
+#endif
     }
   });
   ASM_STAMP(40);
