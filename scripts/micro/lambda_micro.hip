@@ -21,6 +21,20 @@ extern "C" __global__ __launch_bounds__(256, PROBE_OCC) void probe_k(AsmDev d) {
 }
 #endif
 
+// variants 10 / 11: the workgroup kernels of qp_wg.h with EIGHT waves per problem (fp64 / f32), 12 .. 16 blocks
+template <class T> __device__ __forceinline__ void wg8_any(const AsmDev& d, int p) {
+  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
+  switch (max((m + 15) >> 4, 12)) {
+    case 16: asm_lambda_wg<T, 16, 8>(d, p, m); break;
+    case 15: asm_lambda_wg<T, 15, 8>(d, p, m); break;
+    case 14: asm_lambda_wg<T, 14, 8>(d, p, m); break;
+    case 13: asm_lambda_wg<T, 13, 8>(d, p, m); break;
+    default: asm_lambda_wg<T, 12, 8>(d, p, m); break;
+  }
+}
+__global__ __launch_bounds__(512, 1) void wg64_8_k(AsmDev d) { if ((int)blockIdx.x < d.counters[ASM_CNT_BIG64]) wg8_any<double>(d, d.binlist[(size_t)(ASM_NLIST + 1) * d.nseg + blockIdx.x]); }
+__global__ __launch_bounds__(512, 2) void wg32_8_k(AsmDev d) { if ((int)blockIdx.x < d.counters[ASM_CNT_BIG32]) wg8_any<float>(d, d.binlist[(size_t)ASM_NLIST * d.nseg + blockIdx.x]); }
+
 int main(int argc, char** argv) {
   const int m = argc > 1 ? atoi(argv[1]) : 112;
   const int nseg = argc > 2 ? atoi(argv[2]) : 14336;
@@ -62,7 +76,7 @@ int main(int argc, char** argv) {
   int bin = max((m + 15) / 16, 4) - 4; if (bin >= ASM_NBIN) bin = ASM_NBIN - 1;
   int cnt[ASM_NCNT] = {0}; cnt[4 + bin] = nseg; cnt[ASM_CNT_F32 + bin] = nseg; cnt[ASM_CNT_BIG32] = nseg;
   if (variant == 5) { cnt[ASM_CNT_F32 + 6] = cnt[ASM_CNT_F32 + 7] = 0; }            // four-wave register kernels (qp_wg.h): one list each
-  if (variant == 6) { cnt[4 + 6] = cnt[4 + 7] = 0; cnt[ASM_CNT_BIG64] = nseg; }
+  if (variant == 6 || variant == 10) { cnt[4 + 6] = cnt[4 + 7] = 0; cnt[ASM_CNT_BIG64] = nseg; }
   CK(hipMalloc(&dcnt, sizeof cnt)); CK(hipMemcpy(dcnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
   CK(hipMalloc(&dbin, (size_t)(ASM_NLIST + 2) * nseg * 4));
   for (int b = 0; b <= ASM_NLIST + 1; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
@@ -96,6 +110,8 @@ int main(int argc, char** argv) {
     else if (variant == 8) hipLaunchKernelGGL(asm_lambda_wg64s_k, dim3(nseg), dim3(128), asm_wg_lds_bytes<double>(), 0, d);
     else if (variant == 5) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<float>(), 0, d);
     else if (variant == 6) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<double>(), 0, d);
+    else if (variant == 10) hipLaunchKernelGGL(wg64_8_k, dim3(nseg), dim3(512), asm_wg_lds_bytes<double>(), 0, d);
+    else if (variant == 11) hipLaunchKernelGGL(wg32_8_k, dim3(nseg), dim3(512), asm_wg_lds_bytes<float>(), 0, d);
     else if (variant == 4) {                                  // f32 LDS-tile workgroup kernel (177..256 bounds)
       static bool once4 = false;
       if (!once4) { CK(hipFuncSetAttribute((const void*)asm_lambda_tile32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_TILE32_LDS)); once4 = true; }
@@ -128,7 +144,7 @@ int main(int argc, char** argv) {
   double worst = 0.0;
   for (int pp = 0; pp < 2; ++pp) {
     const int p = pp == 0 ? 0 : nseg - 1;
-    if (variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7) {
+    if (variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 11) {
       std::vector<float> l32(np);
       CK(hipMemcpy(l32.data(), dlam32 + (size_t)p * np, np * 4, hipMemcpyDeviceToHost));
       for (int i = 0; i < np; ++i) lam[i] = l32[i];
