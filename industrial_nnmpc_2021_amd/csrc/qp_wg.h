@@ -32,15 +32,17 @@ constexpr int ASM_WG_MB = 16;                              // blocks of the larg
 #define ASM_WG_GUARD64 13
 #endif
 constexpr int ASM_WG_MAX = 16 * ASM_WG_MB;
+constexpr int ASM_WG_MB8 = 24;                             // ... of the eight-wave f32 instances (257 .. 384 bounds)
 __host__ __device__ constexpr int asm_wg_off(int MB, int NW, int a) { int o = 0; for (int b = 0; b < a; ++b) o += MB - NW * b; return o; }   // first tile of slot a
 __host__ __device__ constexpr int asm_wg_tiles(int MB, int NW) { return asm_wg_off(MB, NW, (MB + NW - 1) / NW); }
 __host__ __device__ constexpr int asm_wg_owner(int MB, int NW, int K) {   // wave that owns block row K (its slot: (MB - 1 - K) / NW)
   const int rp = MB - 1 - K, a = rp / NW;
   return (a & 1) ? NW - 1 - rp % NW : rp % NW;
 }
-// LDS, in elements of T: diagonal tile, its inverse, identity tile | y [256] | rhs [256] | partial sums [2][8 waves][16] |
-// panel [16 + 1][256] (tile 16: where the rows above the diagonal go); then ints: index list [256], flag
-template <class T> constexpr int asm_wg_lds_bytes() { return (3 * ASM_TS + 256 + 256 + 256 + 17 * 256) * (int)sizeof(T) + (256 + 4) * 4; }
+// LDS, in elements of T: diagonal tile, its inverse, identity tile | y [ROWS] | rhs [ROWS] | partial sums [2][8 waves][16] |
+// panel [MB8 + 1][256] (the last tile: where the rows above the diagonal go); then ints: index list [ROWS], flag
+// (MBX: the largest number of blocks of the kernel's instances -- 16 for the four- and two-wave kernels, 24 for the eight-wave one)
+template <class T, int MBX = ASM_WG_MB> constexpr int asm_wg_lds_bytes() { return (3 * ASM_TS + 2 * 16 * MBX + 256 + (MBX + 1) * 256) * (int)sizeof(T) + (16 * MBX + 4) * 4; }
 
 template <class T, int MB, int NW>
 __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
@@ -56,11 +58,13 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
   T* Yt = dt + ASM_TS;                                     // its inverse factor
   T* idt = Yt + ASM_TS;                                    // identity tile
   T* ys = idt + ASM_TS;                                    // y (forward result) [16][16]
-  T* rv = ys + 256;                                        // right-hand side
-  T* part = rv + 256;                                      // backward substitution: [2][NW waves][16]
+  constexpr int MBX = MB > ASM_WG_MB ? ASM_WG_MB8 : ASM_WG_MB, ROWS = 16 * MBX;   // (the LDS layout of the kernel this instance belongs to)
+  T* rv = ys + ROWS;                                       // right-hand side
+  T* part = rv + ROWS;                                     // backward substitution: [2][NW waves][16]
   T* panel = part + 256;                                   // L(J,K), J > K, of the current block column: tile J at 256 J, lane-major V4
-  int* ix = reinterpret_cast<int*>(panel + 17 * 256);      // active indices (padded with the last one)
-  int* s_bad = ix + 256;
+  int* ix = reinterpret_cast<int*>(panel + (MBX + 1) * 256);   // active indices (padded with the last one)
+  int* s_bad = ix + ROWS;
+  constexpr int PSPARE = MBX;                              // panel tile that takes the rows above the diagonal
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const size_t o = (size_t)p * d.np;
@@ -70,7 +74,7 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
   const int wg = blockIdx.x;
 #endif
   ASM_STAMP(0);
-  for (int i = tid; i < 256; i += NTH) {
+  for (int i = tid; i < 16 * MB; i += NTH) {
     const int a = idx[min(i, m - 1)], k = a % d.nu;
     ix[i] = a;
     const double v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
@@ -186,7 +190,7 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) { C[oa + K][r] = (GUARD || real) ? acc[r] : b[r]; dot += acc[r] * yq[r]; }
               ps[a] += (GUARD || real) ? dot : T(0);
-              *reinterpret_cast<V4*>(panel + ((GUARD || real) ? Ia[a] : 16) * 256 + lane * 4) = acc;
+              *reinterpret_cast<V4*>(panel + ((GUARD || real) ? Ia[a] : PSPARE) * 256 + lane * 4) = acc;
             }
           }
         });
@@ -239,7 +243,13 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
           if constexpr (K + 1 + c < MB) trailing(asm_ic<1>{}, asm_ic<K + 1 + c>{});
           __builtin_amdgcn_sched_barrier(0);
         });
-        static_assert(MB <= 17, "one block column of the trailing update per pivot step");
+        // (more than 17 blocks: the block columns beyond the sixteenth after the chain)
+        if constexpr (K + 17 < MB) {
+          asm_sfor<K + 17, MB>([&](auto Jc) __attribute__((always_inline)) {
+            trailing(asm_ic<1>{}, Jc);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
         ASM_STAMP(6 + 3 * (K % 9));
         bad |= asm_diag16_end<T>(x, Yt, lane);
         ASM_FENCE();
@@ -342,6 +352,26 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_wg32_k(AsmDev d) {
 }
 __global__ __launch_bounds__(256, 1) void asm_lambda_wg64_k(AsmDev d) {
   if ((int)blockIdx.x < d.counters[ASM_CNT_BIG64]) asm_lambda_wg_any<double>(d, d.binlist[(size_t)(ASM_NLIST + 1) * d.nseg + blockIdx.x]);
+}
+
+// f32 rounds of the sets of 257 .. 384 bounds (list ASM_NLIST + 2): EIGHT waves per problem, one workgroup per CU.  Until round 4
+// these sets ran every round -- f32 or not -- in the fp64 L2-slab kernel (1.9 us per solve at 290 bounds); an f32 result only moves
+// the set, and the tiles of 17 .. 24 blocks fit the registers of eight waves in f32 (153 .. 300 tiles: at most 48 per wave).
+__global__ __launch_bounds__(512, 1) void asm_lambda_wg32b_k(AsmDev d) {
+  if ((int)blockIdx.x >= d.counters[ASM_CNT_BIG32B]) return;
+  const int p = d.binlist[(size_t)(ASM_NLIST + 2) * d.nseg + blockIdx.x];
+  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
+  if (m <= 256 || m > ASM_BIG32B) return;
+  switch ((m + 15) >> 4) {
+    case 24: asm_lambda_wg<float, 24, 8>(d, p, m); break;
+    case 23: asm_lambda_wg<float, 23, 8>(d, p, m); break;
+    case 22: asm_lambda_wg<float, 22, 8>(d, p, m); break;
+    case 21: asm_lambda_wg<float, 21, 8>(d, p, m); break;
+    case 20: asm_lambda_wg<float, 20, 8>(d, p, m); break;
+    case 19: asm_lambda_wg<float, 19, 8>(d, p, m); break;
+    case 18: asm_lambda_wg<float, 18, 8>(d, p, m); break;
+    default: asm_lambda_wg<float, 17, 8>(d, p, m); break;
+  }
 }
 
 // The 10- and 11-block classes (145 .. 176 bounds) with TWO waves per problem: the same number of problems per CU as the

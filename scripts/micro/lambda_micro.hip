@@ -76,10 +76,11 @@ int main(int argc, char** argv) {
   int bin = max((m + 15) / 16, 4) - 4; if (bin >= ASM_NBIN) bin = ASM_NBIN - 1;
   int cnt[ASM_NCNT] = {0}; cnt[4 + bin] = nseg; cnt[ASM_CNT_F32 + bin] = nseg; cnt[ASM_CNT_BIG32] = nseg;
   if (variant == 5) { cnt[ASM_CNT_F32 + 6] = cnt[ASM_CNT_F32 + 7] = 0; }            // four-wave register kernels (qp_wg.h): one list each
+  if (variant == 12) cnt[ASM_CNT_BIG32B] = nseg;             // eight-wave f32 kernel of the solver: 257 .. 384 bounds
   if (variant == 6 || variant == 10) { cnt[4 + 6] = cnt[4 + 7] = 0; cnt[ASM_CNT_BIG64] = nseg; }
   CK(hipMalloc(&dcnt, sizeof cnt)); CK(hipMemcpy(dcnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
-  CK(hipMalloc(&dbin, (size_t)(ASM_NLIST + 2) * nseg * 4));
-  for (int b = 0; b <= ASM_NLIST + 1; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dbin, (size_t)(ASM_NLIST + 3) * nseg * 4));
+  for (int b = 0; b <= ASM_NLIST + 2; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&didx, idx.size() * 4)); CK(hipMemcpy(didx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&dmg, nseg * 4)); CK(hipMemcpy(dmg, mg.data(), nseg * 4, hipMemcpyHostToDevice));
   d.H = dH; d.lb = dlb; d.ub = dub; d.xunc = dxu; d.lam = dlam; d.st = dst; d.state = dstate; d.counters = dcnt;
@@ -110,6 +111,7 @@ int main(int argc, char** argv) {
     else if (variant == 8) hipLaunchKernelGGL(asm_lambda_wg64s_k, dim3(nseg), dim3(128), asm_wg_lds_bytes<double>(), 0, d);
     else if (variant == 5) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<float>(), 0, d);
     else if (variant == 6) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<double>(), 0, d);
+    else if (variant == 12) hipLaunchKernelGGL(asm_lambda_wg32b_k, dim3(nseg), dim3(512), (asm_wg_lds_bytes<float, ASM_WG_MB8>()), 0, d);
     else if (variant == 10) hipLaunchKernelGGL(wg64_8_k, dim3(nseg), dim3(512), asm_wg_lds_bytes<double>(), 0, d);
     else if (variant == 11) hipLaunchKernelGGL(wg32_8_k, dim3(nseg), dim3(512), asm_wg_lds_bytes<float>(), 0, d);
     else if (variant == 4) {                                  // f32 LDS-tile workgroup kernel (177..256 bounds)
@@ -144,7 +146,7 @@ int main(int argc, char** argv) {
   double worst = 0.0;
   for (int pp = 0; pp < 2; ++pp) {
     const int p = pp == 0 ? 0 : nseg - 1;
-    if (variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 11) {
+    if (variant == 2 || variant == 3 || variant == 4 || variant == 5 || variant == 7 || variant == 11 || variant == 12) {
       std::vector<float> l32(np);
       CK(hipMemcpy(l32.data(), dlam32 + (size_t)p * np, np * 4, hipMemcpyDeviceToHost));
       for (int i = 0; i < np; ++i) lam[i] = l32[i];
