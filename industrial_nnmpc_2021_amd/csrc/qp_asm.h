@@ -46,6 +46,7 @@ constexpr int ASM_CNT_BIG64 = 37;         // counters[37]: length of list ASM_NL
 constexpr int ASM_CNT_BIG32 = 36;         // counters[36]: length of list ASM_NLIST
 constexpr int ASM_BIG32B = 384;           // largest set whose f32 rounds run in registers at all: 257 .. 384 bounds on EIGHT waves per problem
                                           // (asm_lambda_wg32b_k, qp_wg.h); beyond, and for every fp64 solve beyond 256: the L2-slab kernel
+constexpr int ASM_CNT_BIG64R = 31;        // counters[31]: length of list ASM_NLIST + 3 (fp64 solves of sets of 257 .. 384 bounds: f32 factor + fp64 refinement)
 constexpr int ASM_CNT_BIG32B = 39;        // counters[39]: length of list ASM_NLIST + 2 (f32 rounds of sets of 257 .. 384 bounds)
 constexpr int ASM_GRACE = 10;       // rounds without a new minimum of infeasible indices before single exchanges take over
 constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last asm_wide_k, counters[ASM_CNT_WKSUM]: the sum of their
@@ -57,12 +58,12 @@ constexpr int ASM_CNT_DONE = 14;   // counters[14]: problems finished but not ce
 // list `list` of AsmDev::binlist and its length: 0..ASM_NBIN-1 the fp64 size classes (counters[4 + b]),
 // ASM_NBIN + b the f32 ones (counters[ASM_CNT_F32 + b])
 __host__ __device__ constexpr int asm_list_counter(int list) {
-  return list < ASM_NBIN ? 4 + list : (list < ASM_NLIST ? ASM_CNT_F32 + list - ASM_NBIN : (list == ASM_NLIST ? ASM_CNT_BIG32 : (list == ASM_NLIST + 1 ? ASM_CNT_BIG64 : ASM_CNT_BIG32B)));
+  return list < ASM_NBIN ? 4 + list : (list < ASM_NLIST ? ASM_CNT_F32 + list - ASM_NBIN : (list == ASM_NLIST ? ASM_CNT_BIG32 : (list == ASM_NLIST + 1 ? ASM_CNT_BIG64 : (list == ASM_NLIST + 2 ? ASM_CNT_BIG32B : ASM_CNT_BIG64R))));
 }
 __host__ __device__ constexpr int asm_list_of_counter(int c) { return c >= ASM_CNT_F32 ? ASM_NBIN + c - ASM_CNT_F32 : c - 4; }   // size-class lists only
 constexpr int ASM_NKG = 3;         // rows of a round are ordered by the last active stage (groups: <= median, +1, beyond),
                                    // so that a 128-row block of the GEMM stops its k-loop at ITS last active bound
-constexpr int ASM_NSCAN = ASM_NLIST + 8 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, the problems the
+constexpr int ASM_NSCAN = ASM_NLIST + 9 + 2 * ASM_NKG;  // scan columns: large sets, the lists, (fp64, f32) x group rows, the problems the
                                                         // full-width pass handled (number, sum of last active index + 1), sum and max of
                                                         // the last active indices of the running problems
 constexpr int ASM_CNT_ROWS32 = 15; // counters[15]: rows of LAM32 / XH32 handed out ([2]: rows of LAM / XH)
@@ -313,16 +314,16 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
 // counters: [2] / [ASM_CNT_ROWS32] running problems solved in fp64 / f32 this round (the host adds them up), [1] sets too large for LDS, [3] largest active variable index, [4 + b] length
 // of size-class list b.  counters[ASM_CNT_WIDEG..] (filled by asm_update_k, consumed by asm_wide_k earlier in
 // the round) is reset here.
-// scan columns: 0 large sets, 1 + list (lists 0 .. ASM_NLIST + 2), ASM_COL_ROW + prec * ASM_NKG + group (rows of LAM / LAM32), then the sum of
+// scan columns: 0 large sets, 1 + list (lists 0 .. ASM_NLIST + 3), ASM_COL_ROW + prec * ASM_NKG + group (rows of LAM / LAM32), then the sum of
 // (last active index + 1) and the max index
-constexpr int ASM_COL_ROW = 4 + ASM_NLIST;
+constexpr int ASM_COL_ROW = 5 + ASM_NLIST;
 constexpr int ASM_COL_WCNT = ASM_COL_ROW + 2 * ASM_NKG, ASM_COL_WK = ASM_COL_WCNT + 1;
 constexpr int ASM_WG_SETS = 256;   // largest set of the four-wave register kernels (qp_wg.h)
 __device__ __forceinline__ int asm_scan_col(const AsmDev& d, int p, bool& run) {   // 0 large set, 1 + list otherwise
   run = p < d.nseg && d.state[p] == ASM_RUN;
   if (!run) return -1;
   const int m = d.mg[p];
-  if (m > ASM_MLDS) return (d.prec[p] == 0 && m <= ASM_BIG32) ? 1 + ASM_NLIST : ((d.use_wg && m <= ASM_WG_SETS) ? 2 + ASM_NLIST : ((d.use_wg && d.prec[p] == 0 && m <= ASM_BIG32B) ? 3 + ASM_NLIST : 0));
+  if (m > ASM_MLDS) return (d.prec[p] == 0 && m <= ASM_BIG32) ? 1 + ASM_NLIST : ((d.use_wg && m <= ASM_WG_SETS) ? 2 + ASM_NLIST : ((d.use_wg && d.prec[p] == 0 && m <= ASM_BIG32B) ? 3 + ASM_NLIST : ((d.use_wg && d.prec[p] == 1 && m <= ASM_BIG32B) ? 4 + ASM_NLIST : 0)));   // (prec 2: the refinement gave up on this set)
   const int b = max((m + 15) / 16, 4) - 4;
   return 1 + (d.prec[p] == 0 ? ASM_NBIN + b : b);
 }
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
     if (lane == 0) wtot[ASM_COL_ROW + c][wave] = __popcll(mk);
   }
 #pragma unroll
-  for (int c = 0; c <= ASM_NLIST + 3; ++c) {
+  for (int c = 0; c <= ASM_NLIST + 4; ++c) {
     const unsigned long long mk = __ballot(col == c);
     if (col == c) myrank = __popcll(mk & lt);
     if (lane == 0) wtot[c][wave] = __popcll(mk);
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
     else if (tid == ASM_COL_WCNT) d.counters[ASM_CNT_WIDE + 1] = total[tid];
     else if (tid == ASM_COL_WK) d.counters[ASM_CNT_WKSUM] = total[tid];
     else if (tid == 0) d.counters[1] = total[0];
-    else if (tid <= ASM_NLIST + 3) d.counters[asm_list_counter(tid - 1)] = total[tid];
+    else if (tid <= ASM_NLIST + 4) d.counters[asm_list_counter(tid - 1)] = total[tid];
     else if (tid == ASM_COL_ROW) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + g]; d.counters[2] = t; }
     else if (tid == ASM_COL_ROW + ASM_NKG) { int t = 0; for (int g = 0; g < ASM_NKG; ++g) t += total[ASM_COL_ROW + ASM_NKG + g]; d.counters[ASM_CNT_ROWS32] = t; }
   }

@@ -1342,11 +1342,12 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       const int nwg64 = a.use_wg ? cnt[ASM_CNT_BIG64] : 0;
       const int nwg32 = a.use_wg ? cnt[ASM_CNT_BIG32] : 0;
       const int nwg32b = a.use_wg ? cnt[ASM_CNT_BIG32B] : 0;   // f32 rounds of 257 .. 384 bounds: eight waves per problem
-      int nbig = cnt[1] + cnt[ASM_CNT_BIG32] + nreg2_wg + nreg32b_wg + nwg64 + nwg32b, nreg_wg = 0, nreg32_wg = 0;
+      const int nwg64r = a.use_wg ? cnt[ASM_CNT_BIG64R] : 0;   // ... and their fp64 solves: the same factorisation, refined to fp64 residuals
+      int nbig = cnt[1] + cnt[ASM_CNT_BIG32] + nreg2_wg + nreg32b_wg + nwg64 + nwg32b + nwg64r, nreg_wg = 0, nreg32_wg = 0;
       for (int b = 0; b < ASM_NREG; ++b) { nreg_wg += (cnt[4 + b] + 3) / 4; nreg32_wg += (cnt[ASM_CNT_F32 + b] + 3) / 4; }
       // three side streams: [slab kernel: few workgroups, long chains -- it starts first and runs beside everything else],
       // [four-wave kernels of the 12 .. 16-block sets], [single-wave kernels of the 10- and 11-block classes]
-      const bool side4 = cnt[1] > 0, side2 = nwg64 + nwg32 + nwg32b > 0 || (cnt[ASM_CNT_BIG32] && !a.use_wg), side3 = nreg2_wg + nreg32b_wg > 0;
+      const bool side4 = cnt[1] > 0, side2 = nwg64 + nwg32 + nwg32b + nwg64r > 0 || (cnt[ASM_CNT_BIG32] && !a.use_wg), side3 = nreg2_wg + nreg32b_wg > 0;
       if (nbig) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         if (side4) {
@@ -1358,6 +1359,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
           HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
           EvScope e9(h, 9, 0.0, h->stream2);
           if (nwg64) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nwg64), dim3(256), asm_wg_lds_bytes<double>(), h->stream2, a);
+          if (nwg64r) hipLaunchKernelGGL(asm_lambda_wg64r_k, dim3(nwg64r), dim3(512), (asm_wg_lds_bytes_refine<float, ASM_WG_MB8>()), h->stream2, a);
           if (nwg32b) hipLaunchKernelGGL(asm_lambda_wg32b_k, dim3(nwg32b), dim3(512), (asm_wg_lds_bytes<float, ASM_WG_MB8>()), h->stream2, a);
           if (nwg32) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nwg32), dim3(256), asm_wg_lds_bytes<float>(), h->stream2, a);
           if (cnt[ASM_CNT_BIG32] && !a.use_wg) hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(cnt[ASM_CNT_BIG32], 4096)), dim3(512), ASM_TILE32_LDS, h->stream2, a);
@@ -1607,7 +1609,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(h->asm_xhw, (G + 256) * np); A_(h->asm_rowprob, G + 256); A_(h->asm_wflag, G); A_(h->asm_wmark, G);
   A_(h->asm_tnorm, G + 128 * (ASM_NKG + 1)); A_(h->asm_tslack, G + 128 * (ASM_NKG + 1));
   A_(h->asm_st, G * n); A_(h->asm_state, G); A_(h->asm_rounds, G); A_(h->asm_counters, ASM_NCNT);
-  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 3) * G);
+  A_(h->asm_biglist, G); A_(h->asm_status, G); A_(h->asm_binlist, (size_t)(ASM_NLIST + 4) * G);
   A_(h->asm_idxg, G * o.asm_max_active); A_(h->asm_mg, G); A_(h->asm_row, G); A_(h->asm_lrank, G); A_(h->asm_ctot, ((G + 1023) / 1024) * ASM_NSCAN); A_(h->asm_prec, G); A_(h->asm_redo, G); A_(h->asm_rowk, G); A_(h->asm_lam32, G * np); A_(h->asm_xh32, G * np); A_(h->asm_alpha, G); A_(h->asm_ninf, G); A_(h->asm_hi, G); A_(h->asm_kblk, 2 * (G / 64 + 2)); A_(h->asm_work, 3 * G);
   A_(h->asm_scratch, (size_t)h->asm_pool * ((size_t)(o.asm_max_active / 16) * (o.asm_max_active / 16 + 1) / 2 * ASM_TS));
 #undef A_

@@ -42,9 +42,16 @@ __host__ __device__ constexpr int asm_wg_owner(int MB, int NW, int K) {   // wav
 // LDS, in elements of T: diagonal tile, its inverse, identity tile | y [ROWS] | rhs [ROWS] | partial sums [2][8 waves][16] |
 // panel [MB8 + 1][256] (the last tile: where the rows above the diagonal go); then ints: index list [ROWS], flag
 // (MBX: the largest number of blocks of the kernel's instances -- 16 for the four- and two-wave kernels, 24 for the eight-wave one)
+template <class T, int MBX> constexpr int asm_wg_lds_bytes_refine();
 template <class T, int MBX = ASM_WG_MB> constexpr int asm_wg_lds_bytes() { return (3 * ASM_TS + 2 * 16 * MBX + 256 + (MBX + 1) * 256) * (int)sizeof(T) + (16 * MBX + 4) * 4; }
 
-template <class T, int MB, int NW>
+// REFINE (f32 instances only): the fp64 solve of a set too large for fp64 tiles in registers -- the f32 factor stays in the
+// registers and the multipliers are refined against fp64 residuals  r = b - S lam  (S gathered again from the fp64 inverse, row by
+// row, lanes along the row; b, lam, r in fp64) until max |r| <= 1e-13 max |b|: an fp64 RESULT from f32 arithmetic on the tiles.
+// A set it cannot bring there in ASM_WG_NREF corrections (cond(S) 6e-8 per step) is handed to the fp64 slab kernel (prec = 2).
+constexpr int ASM_WG_NREF = 5;
+template <class T, int MBX> constexpr int asm_wg_lds_bytes_refine() { return asm_wg_lds_bytes<T, MBX>() + (2 * 16 * MBX + 16) * 8 + 16; }
+template <class T, int MB, int NW, bool REFINE = false>
 __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
   using N = AsmNum<T>;
   using V4 = typename N::v4;
@@ -64,6 +71,9 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
   T* panel = part + 256;                                   // L(J,K), J > K, of the current block column: tile J at 256 J, lane-major V4
   int* ix = reinterpret_cast<int*>(panel + (MBX + 1) * 256);   // active indices (padded with the last one)
   int* s_bad = ix + ROWS;
+  double* b64 = reinterpret_cast<double*>(s_bad + 4);      // REFINE only (asm_wg_lds_bytes_refine): rhs in fp64 [ROWS], multipliers [ROWS], maxima [2 NW]
+  double* lam64 = b64 + ROWS;
+  double* red = lam64 + ROWS;
   constexpr int PSPARE = MBX;                              // panel tile that takes the rows above the diagonal
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
@@ -79,6 +89,7 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
     ix[i] = a;
     const double v = d.xunc[o + a] - (st[a] == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
     rv[i] = i < m ? (T)v : T(0);
+    if constexpr (REFINE) { b64[i] = i < m ? v : 0.0; lam64[i] = 0.0; }
   }
   for (int j = tid; j < ASM_TS; j += NTH) idt[j] = (j / 17 == j % 17) ? T(1) : T(0);
   if (tid == 0) *s_bad = 0;
@@ -267,13 +278,14 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
   if (*s_bad) {
     // f32: S is not positive definite in this precision -- the round is void (the LAM32 row is still zero), the next one
     // runs in fp64.  fp64: hand the problem to the PDIP path.
-    if (tid == 0) { if (N::F32) { d.prec[p] = 1; d.redo[p] = 1; } else d.state[p] = ASM_FALLBACK; }
+    if (tid == 0) { if (REFINE) { d.prec[p] = 2; d.redo[p] = 1; } else if (N::F32) { d.prec[p] = 1; d.redo[p] = 1; } else d.state[p] = ASM_FALLBACK; }
     return;
   }
-  if (!N::F32 && tid == 0) d.prec[p] = 1;                  // solved in fp64
+  if ((!N::F32 || REFINE) && tid == 0) d.prec[p] = 1;      // solved in fp64 (REFINE: to fp64 residuals)
   // ---- backward substitution  L' lam = y:  lam_K = Y_K' (y_K - sum_{I>K} L(I,K)' lam_I), the sum over the rows of all four
   // waves through LDS (double-buffered by the parity of K: one barrier per block column)
   T lam[NS];
+  auto backward = [&]() __attribute__((always_inline)) {
 #pragma unroll
   for (int a = 0; a < NS; ++a) lam[a] = T(0);
   asm_sfor<0, MB>([&](auto Kr) __attribute__((always_inline)) {
@@ -311,6 +323,109 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
       lam[aK] = xsum4<T>(acc);
     }
   });
+  };
+  backward();
+  if constexpr (REFINE) {
+    // ---- fp64 refinement on the f32 factor
+    bool conv = false;
+    for (int itr = 0; itr <= ASM_WG_NREF && !conv; ++itr) {
+      // lam64 += the correction just solved for (the first pass: the f32 solution itself)
+#pragma unroll
+      for (int a = 0; a < NS; ++a) {
+        const int i = 16 * Ia[a] + li;
+        if (Ia[a] >= 0 && lq == 0 && i < m) lam64[i] += (double)lam[a];
+      }
+      __syncthreads();
+      // r = b - S lam64: row i by wave i % NW, lanes along the row (the gathered entries of one row of the inverse lie within a few KB)
+      double rmax = 0.0, bmax = 0.0;
+      // (four rows at a time: their gathers -- L2 / Infinity Cache round trips -- are all in flight before the first product; one row
+      // at a time the loop was a chain of ~0.5 us waits, 20 us per residual)
+      for (int i0 = wave; i0 < 16 * MB; i0 += 4 * NW) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const double* Hr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Hr[u] = d.H + (size_t)ix[min(i0 + u * NW, m - 1)] * d.np;
+        for (int j = lane; j < m; j += 64) {
+          const int cj = ix[j];
+          const double lj = lam64[j];
+          double hv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) hv[u] = Hr[u][cj];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] += hv[u] * lj;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NW;
+          if (i < 16 * MB) {
+            const double r = i < m ? b64[i] - acc[u] : 0.0;
+            if (lane == 0) rv[i] = (T)r;
+            rmax = fmax(rmax, fabs(r)); bmax = fmax(bmax, i < m ? fabs(b64[i]) : 0.0);
+          }
+        }
+      }
+      if (lane == 0) { red[wave] = rmax; red[NW + wave] = bmax; }
+      __syncthreads();
+      double rm = 0.0, bm = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { rm = fmax(rm, red[w]); bm = fmax(bm, red[NW + w]); }
+      conv = rm <= 1e-13 * bm || !(rm == rm);             // (a NaN leaves the loop: handled below)
+      if (!(rm == rm)) { conv = false; break; }
+      if (conv || itr == ASM_WG_NREF) break;
+      // correction: forward substitution of r (the stored L and Y_K, one barrier per block column), then backward
+      T ps2[NS];
+#pragma unroll
+      for (int a = 0; a < NS; ++a) ps2[a] = T(0);
+      asm_sfor<0, MB>([&](auto Kc) __attribute__((always_inline)) {
+        constexpr int K = decltype(Kc)::value;
+        constexpr int aK = (MB - 1 - K) / NW, wK = asm_wg_owner(MB, NW, K), oK = asm_wg_off(MB, NW, aK);
+        if (wave == wK) {
+          const V4 Yc = C[oK + K];
+          const T tK = rv[16 * K + li] - (K ? xsum4<T>(ps2[aK]) : T(0));
+          T yq[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yq[r] = Yc[r] * tK;
+          rowsum16x4<T>(yq);
+          if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ys[16 * K + N::kr(lq, r)] = yq[r];
+          }
+        }
+        __syncthreads();
+        if constexpr (K + 1 < MB) {
+          T yq[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) yq[s4] = ys[16 * K + N::kr(lq, s4)];
+          asm_sfor<0, NS>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int a = decltype(ac)::value;
+            constexpr int oa = asm_wg_off(MB, NW, a);
+            if constexpr (K < MB - NW * a) {
+              if (Ia[a] > K) {
+                T dot = T(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dot += C[oa + K][r] * yq[r];
+                ps2[a] += dot;
+              }
+            }
+          });
+        }
+      });
+      __syncthreads();
+      backward();
+    }
+    if (!conv) {                                           // not brought to fp64 residuals: the round is void, the slab kernel takes the set
+      if (tid == 0) { d.prec[p] = 2; d.redo[p] = 1; }
+      return;
+    }
+    double* lrow64 = d.lam + (size_t)d.row[p] * d.np;
+    for (int i = tid; i < m; i += NTH) lrow64[ix[i]] = lam64[i];
+    return;
+  }
   ASM_STAMP(41);
   using LT = typename std::conditional<N::F32, float, double>::type;   // f32 rounds: row of LAM32 (f32 GEMM)
   LT* lrow = (N::F32 ? (LT*)d.lam32 : (LT*)d.lam) + (size_t)d.row[p] * d.np;
@@ -371,6 +486,25 @@ __global__ __launch_bounds__(512, 1) void asm_lambda_wg32b_k(AsmDev d) {
     case 19: asm_lambda_wg<float, 19, 8>(d, p, m); break;
     case 18: asm_lambda_wg<float, 18, 8>(d, p, m); break;
     default: asm_lambda_wg<float, 17, 8>(d, p, m); break;
+  }
+}
+
+// fp64 solves of the sets of 257 .. 384 bounds (list ASM_NLIST + 3): the same eight-wave f32 factorisation, refined to fp64
+// residuals (REFINE above).  Replaces the fp64 L2-slab kernel there (1.9 us per solve at 290 bounds).
+__global__ __launch_bounds__(512, 1) void asm_lambda_wg64r_k(AsmDev d) {
+  if ((int)blockIdx.x >= d.counters[ASM_CNT_BIG64R]) return;
+  const int p = d.binlist[(size_t)(ASM_NLIST + 3) * d.nseg + blockIdx.x];
+  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
+  if (m <= 256 || m > ASM_BIG32B) return;
+  switch ((m + 15) >> 4) {
+    case 24: asm_lambda_wg<float, 24, 8, true>(d, p, m); break;
+    case 23: asm_lambda_wg<float, 23, 8, true>(d, p, m); break;
+    case 22: asm_lambda_wg<float, 22, 8, true>(d, p, m); break;
+    case 21: asm_lambda_wg<float, 21, 8, true>(d, p, m); break;
+    case 20: asm_lambda_wg<float, 20, 8, true>(d, p, m); break;
+    case 19: asm_lambda_wg<float, 19, 8, true>(d, p, m); break;
+    case 18: asm_lambda_wg<float, 18, 8, true>(d, p, m); break;
+    default: asm_lambda_wg<float, 17, 8, true>(d, p, m); break;
   }
 }
 
