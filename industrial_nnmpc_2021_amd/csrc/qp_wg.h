@@ -508,6 +508,26 @@ __global__ __launch_bounds__(512, 1) void asm_lambda_wg64r_k(AsmDev d) {
   }
 }
 
+// (The same for the sets of 177 .. 256 bounds -- four waves, f32 tiles, two workgroups per CU, refined -- is no faster than the fp64
+// register kernel asm_lambda_wg64_k there: 4.4 / 3.0 / 2.5 against 4.3 / 3.3 / 2.3 problems per microsecond at 192 / 224 / 256
+// bounds (scripts/micro/lambda_micro.hip, variant 14 against 6): the three residual passes and two extra solves cost what the f32
+// tiles save.  Not instantiated in the library.)
+#ifdef ASM_WG_MICRO
+__global__ __launch_bounds__(256, 2) void asm_lambda_wg64r4_k(AsmDev d) {
+  if ((int)blockIdx.x >= d.counters[ASM_CNT_BIG64]) return;
+  const int p = d.binlist[(size_t)(ASM_NLIST + 1) * d.nseg + blockIdx.x];
+  const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
+  if (m <= 176 || m > ASM_WG_MAX) return;
+  switch ((m + 15) >> 4) {
+    case 16: asm_lambda_wg<float, 16, 4, true>(d, p, m); break;
+    case 15: asm_lambda_wg<float, 15, 4, true>(d, p, m); break;
+    case 14: asm_lambda_wg<float, 14, 4, true>(d, p, m); break;
+    case 13: asm_lambda_wg<float, 13, 4, true>(d, p, m); break;
+    default: asm_lambda_wg<float, 12, 4, true>(d, p, m); break;
+  }
+}
+#endif
+
 // The 10- and 11-block classes (145 .. 176 bounds) with TWO waves per problem: the same number of problems per CU as the
 // single-wave kernels (four in f32, two in fp64), half the tiles and half the trailing update per wave.  The solver uses the
 // fp64 instance (7.3 / 5.2 problems per microsecond at 160 / 176 bounds, asm_lambda_reg2_k: 6.0 / 4.5); the f32 instance

@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
   if (variant == 5) { cnt[ASM_CNT_F32 + 6] = cnt[ASM_CNT_F32 + 7] = 0; }            // four-wave register kernels (qp_wg.h): one list each
   if (variant == 13) cnt[ASM_CNT_BIG64R] = nseg;             // ... and its refined (fp64-residual) instance
   if (variant == 12) cnt[ASM_CNT_BIG32B] = nseg;             // eight-wave f32 kernel of the solver: 257 .. 384 bounds
-  if (variant == 6 || variant == 10) { cnt[4 + 6] = cnt[4 + 7] = 0; cnt[ASM_CNT_BIG64] = nseg; }
+  if (variant == 6 || variant == 10 || variant == 14) { cnt[4 + 6] = cnt[4 + 7] = 0; cnt[ASM_CNT_BIG64] = nseg; }
   CK(hipMalloc(&dcnt, sizeof cnt)); CK(hipMemcpy(dcnt, cnt, sizeof cnt, hipMemcpyHostToDevice));
   CK(hipMalloc(&dbin, (size_t)(ASM_NLIST + 4) * nseg * 4));
   for (int b = 0; b <= ASM_NLIST + 3; ++b) CK(hipMemcpy(dbin + (size_t)b * nseg, list.data(), nseg * 4, hipMemcpyHostToDevice));
@@ -112,6 +112,7 @@ int main(int argc, char** argv) {
     else if (variant == 8) hipLaunchKernelGGL(asm_lambda_wg64s_k, dim3(nseg), dim3(128), asm_wg_lds_bytes<double>(), 0, d);
     else if (variant == 5) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<float>(), 0, d);
     else if (variant == 6) hipLaunchKernelGGL(asm_lambda_wg64_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<double>(), 0, d);
+    else if (variant == 14) hipLaunchKernelGGL(asm_lambda_wg64r4_k, dim3(nseg), dim3(256), (asm_wg_lds_bytes_refine<float, ASM_WG_MB>()), 0, d);
     else if (variant == 13) hipLaunchKernelGGL(asm_lambda_wg64r_k, dim3(nseg), dim3(512), (asm_wg_lds_bytes_refine<float, ASM_WG_MB8>()), 0, d);
     else if (variant == 12) hipLaunchKernelGGL(asm_lambda_wg32b_k, dim3(nseg), dim3(512), (asm_wg_lds_bytes<float, ASM_WG_MB8>()), 0, d);
     else if (variant == 10) hipLaunchKernelGGL(wg64_8_k, dim3(nseg), dim3(512), asm_wg_lds_bytes<double>(), 0, d);
