@@ -1314,7 +1314,9 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg32b_k(AsmDev d) {
 }
 
 }  // namespace nnmpc
+#ifndef ASM_NO_WG_KERNELS             // (scripts/micro/predict_micro.hip: the workgroup kernels are minutes of compile time)
 #include "qp_wg.h"
+#endif
 namespace nnmpc {
 
 // x from the GEMM result, fp64 KKT tests, next active set.  A problem whose set no longer changes

@@ -10,6 +10,9 @@
 //      x   = x_unc - H y                                  (MFMA: Y[rows][W] x H[W][W], bf16 operands, f32 accumulate)
 //      v   = y + t x,    mu+ = v - clip(v, t lb, t ub)     (the prox of t sigma_box: exact, elementwise)
 //      y+  = mu+ + beta_k (mu+ - mu)                      (Nesterov momentum)
+// Momentum with ADAPTIVE RESTART (O'Donoghue & Candes 2015, gradient scheme), by workgroup and one iteration late: when
+// sum (y - nu+) . (nu+ - nu) > 0 over the workgroup's problems the momentum goes back to zero at the next iteration (Hamming distance
+// of the CDU batch's predicted sets after 24 / 32 iterations: 2.2 / 0.94 plain, 1.4 / 0.18 with the restart; CPU emulation).
 // The kernel iterates on the SCALED multiplier nu = mu / t (t is fixed, so it is the same iteration): with H' = H diag(t) as the MFMA
 // operand,  x = x_unc - H' y,  w = y + x,  nu+ = w - clip(w, lb, ub),  y+ = nu+ + beta (nu+ - nu)  -- no multiplication by t left
 // in the elementwise part, and a w inside the box gives an EXACT zero (w - w): the sign of nu is what names the set.
@@ -63,12 +66,13 @@ struct PredArgs {
                          // (the NT fragments a wave needs for one k-step are NT KB of consecutive memory: pred_frag_index)
   int iters;             // iterations; with `adaptive` the most a workgroup may take
   int* itsum;            // device counter: += iterations after the first of every workgroup (statistics: the executed flops)
+  int fac10;             // adaptive: iterations = fac10 / 10 per bound x_unc violates (per problem, averaged over the workgroup)
   int adaptive;          // 1: every workgroup sets its own count from the bounds x_unc violates in its problems (see asm_predict_k)
   float beta[PRED_MAXIT];   // momentum of iteration k (beta[0] = 0)
 };
 
 template <int NT, int PT> __host__ __device__ constexpr int pred_lds_bytes(int nu) {
-  return 16 * PT * PredCfg<NT>::LDY * 2 + 2 * 16 * PT * (nu + 4) * 4 + 16;      // (nu a multiple of 4; the last 16 bytes: the violation count)
+  return 16 * PT * PredCfg<NT>::LDY * 2 + 2 * 16 * PT * (nu + 4) * 4 + 16;      // (nu a multiple of 4; the last 16 bytes: the violation count, the restart sums)
 }
 
 template <int NT> __host__ __device__ constexpr size_t pred_frag_index(int jtg, int ks, int lane) {   // 16-byte fragment of column tile jtg (0 .. W / 16), k-step ks
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
   float* lbs = reinterpret_cast<float*>(Y + MR * LDY);                         // [MR][nu + 4]
   float* ubs = lbs + MR * ldb;
   int* nviol = reinterpret_cast<int*>(ubs + MR * ldb);                         // bounds x_unc violates, summed over the workgroup's problems
+  float* rsum = reinterpret_cast<float*>(nviol + 1);                           // [2] restart test sums, double-buffered by iteration parity
   constexpr int NTH = 64 * PRED_NW;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
     ubs[r * ldb + k] = (float)d.ub[p * d.nu + k];
   }
   for (int i = tid; i < MR * LDY / 2; i += NTH) reinterpret_cast<unsigned*>(Y)[i] = 0u;
-  if (tid == 0) *nviol = 0;
+  if (tid == 0) { *nviol = 0; rsum[0] = 0.f; rsum[1] = 0.f; }
   // ---- state, in pairs of consecutive columns (packed f32 arithmetic, v_cvt_pk_bf16_f32): sx = x_unc as two f16, sm = mu as two bf16;
   // pair (jt, pt, h): problem 16 pt + li, columns 16 (w NT + jt) + 4 lq + 2 h, + 1
   unsigned sx[NT][PT][2], sm[NT][PT][2];
@@ -140,8 +145,10 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
   // workgroup (its 64 problems come from one batch), between 8 and a.iters.  The count is the number of non-zeros after iteration 0:
   // y = 0 there, so nu+ = x_unc - clip(x_unc, lb, ub).
   int nit = a.iters;
+  int kb = 0;                                                                  // iterations since the momentum was last reset (index into beta)
   for (int it = 0; it < nit; ++it) {
     // ---- x = x_unc - H y on the matrix pipes: acc[jt][pt][r] = sum_k H[col][k] y[problem][k]
+    if (tid == 0) rsum[it & 1] = 0.f;                                            // (this iteration's restart sum: last read an iteration ago; the barrier below orders it)
     pf32x4 acc[NT][PT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
@@ -182,14 +189,19 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
     }
     __syncthreads();                                                             // every wave is done reading Y
     // ---- prox step, momentum, Y rewritten in place (each lane owns its elements)
-    const pf32x2 beta2 = {a.beta[it], a.beta[it]};
-    const bool last = it + 1 == nit;
+    // (restart: decided by the previous iteration's sum, read after that iteration's closing barrier; the other slot is cleared for the
+    // iteration after this one -- it was last read an iteration ago)
+    if (it > 0) kb = rsum[(it - 1) & 1] > 0.f ? 0 : kb + 1;
+    const pf32x2 beta2 = {a.beta[kb], a.beta[kb]};
+    pf32x2 rdot = {0.f, 0.f};
     // (per-lane bases of the LDS accesses below, hidden from the optimiser once per iteration: left alone it hoists ~50 loop-invariant
     // addresses out of the iteration loop and keeps them in scratch memory; from these bases every address is an immediate offset)
-    unsigned short* Yl = Y + li * LDY + 16 * NT * w + 4 * lq;
-    const float* lbl = lbs + li * ldb;
-    const float* ubl = ubs + li * ldb;
-    asm volatile("" : "+v"(Yl), "+v"(lbl), "+v"(ubl));
+    // (the OFFSETS are hidden, not the pointers: a laundered pointer loses its address space and the accesses become flat loads)
+    int yo = li * LDY + 16 * NT * w + 4 * lq, bo = li * ldb;
+    asm volatile("" : "+v"(yo), "+v"(bo));
+    unsigned short* Yl = Y + yo;
+    const float* lbl = lbs + bo;
+    const float* ubl = ubs + bo;
     int nv0 = 0;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -231,48 +243,55 @@ __global__ __launch_bounds__(64 * PRED_NW, 2) void asm_predict_k(AsmDev d, PredA
           const pf32x2 cl = {__builtin_amdgcn_fmed3f(wv[0], lb4[jt & 1][2 * h], ub4[jt & 1][2 * h]),
                              __builtin_amdgcn_fmed3f(wv[1], lb4[jt & 1][2 * h + 1], ub4[jt & 1][2 * h + 1])};
           const pf32x2 nun = wv - cl;
-          const pf32x2 yn = beta2 * (nun - nu) + nun;
+          const pf32x2 dn = nun - nu;
+          const pf32x2 yn = beta2 * dn + nun;
+          rdot += (y - nun) * dn;
           yb[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(yn, pbf16x2));
           sm[jt][pt][h] = __builtin_bit_cast(unsigned, __builtin_convertvector(nun, pbf16x2));
-          if (it == 0) nv0 += ((sm[jt][pt][h] & 0x7fffu) != 0u) + ((sm[jt][pt][h] & 0x7fff0000u) != 0u);
-          if (last) {                                                           // the predicted set: the sign of the multiplier
-            // (nun itself, not its bf16 image; exact zeros come out of the projection)
-            acc[jt][pt][2 * h] = nun[0]; acc[jt][pt][2 * h + 1] = nun[1];
-          }
         }
         *reinterpret_cast<pu32x2*>(yp) = pu32x2{yb[0], yb[1]};
       }
       __builtin_amdgcn_sched_barrier(0);                                         // (one row tile per scheduling region)
     }
-    if (last) {
-      // ---- bound states of the window: 1 upper (mu > 0), 2 lower (mu < 0), 0 free
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        const int c0 = 16 * (w * NT + jt) + 4 * lq;
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          const int p = p0 + 16 * pt + li;
-          unsigned wd = 0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float m = acc[jt][pt][r];
-            wd |= (m > 0.f ? 1u : (m < 0.f ? 2u : 0u)) << (8 * r);
-          }
-          if (p < d.nseg && st_words && c0 + 3 < d.n) *reinterpret_cast<unsigned*>(d.st + (size_t)p * d.n + c0) = wd;
-          else if (p < d.nseg) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (c0 + r < d.n) d.st[(size_t)p * d.n + c0 + r] = (unsigned char)((wd >> (8 * r)) & 0xff);
-          }
-        }
-      }
+    {
+      float rd = rdot[0] + rdot[1];
+      for (int off = 32; off > 0; off >>= 1) rd += __shfl_xor(rd, off);
+      if (lane == 0) atomicAdd(&rsum[it & 1], rd);
     }
     if (it == 0 && a.adaptive) {
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) nv0 += ((sm[jt][pt][h] & 0x7fffu) != 0u) + ((sm[jt][pt][h] & 0x7fff0000u) != 0u);
       for (int off = 32; off > 0; off >>= 1) nv0 += __shfl_xor(nv0, off);
       if (lane == 0 && nv0) atomicAdd(nviol, nv0);
     }
     __syncthreads();                                                             // Y of the next iteration is complete
-    if (it == 0 && a.adaptive) nit = min(a.iters, max(8, (3 * *nviol) / (10 * MR)));
+    if (it == 0 && a.adaptive) nit = min(a.iters, max(8, (a.fac10 * *nviol) / (10 * MR)));
     if (it == 0 && tid == 0 && a.itsum) atomicAdd(a.itsum, nit - 1);
+  }
+  // ---- the predicted set: bound states of the window from the sign of nu -- 1 upper (nu > 0), 2 lower (nu < 0), 0 free.  (From the
+  // bf16 image the state holds: bf16 has the exponent range of f32, a non-zero nu stays non-zero; exact zeros come out of the projection.)
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int c0 = 16 * (w * NT + jt) + 4 * lq;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const int p = p0 + 16 * pt + li;
+      unsigned wd = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned hb16 = (sm[jt][pt][r >> 1] >> (16 * (r & 1))) & 0xffffu;
+        wd |= ((hb16 & 0x7fffu) == 0u ? 0u : ((hb16 >> 15) ? 2u : 1u)) << (8 * r);
+      }
+      if (p < d.nseg && st_words && c0 + 3 < d.n) *reinterpret_cast<unsigned*>(d.st + (size_t)p * d.n + c0) = wd;
+      else if (p < d.nseg) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (c0 + r < d.n) d.st[(size_t)p * d.n + c0 + r] = (unsigned char)((wd >> (8 * r)) & 0xff);
+      }
+    }
   }
 }
 

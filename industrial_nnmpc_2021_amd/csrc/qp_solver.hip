@@ -1089,6 +1089,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     // that one keeps its ~25 iterations: 1.76 ms per step without, 1.94 with the predictor)
     if (iters > 0 && h->pred[0].L > 0.0 && !guess_dev && !small && !tail_only && Wx >= PRED_W) {
       PredArgs pa;
+      { static const int f10 = getenv("NNMPC_PRED_FACTOR") ? atoi(getenv("NNMPC_PRED_FACTOR")) : 3; pa.fac10 = f10; }   // (the variable: diagnostics)
       pa.iters = iters; pa.adaptive = iters_req == 0; pa.itsum = h->profiling ? h->pred_cnt + 1 : nullptr;
       if (h->profiling) HIPCHK(hipMemsetAsync(h->pred_cnt + 1, 0, 4, s));
       double t = 1.0;

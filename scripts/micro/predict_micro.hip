@@ -13,6 +13,7 @@
 #define PRED_MICRO_NT 4
 #define PRED_MICRO_PT 4
 #endif
+#define ASM_NO_WG_KERNELS
 #include "qp_predict.h"
 using namespace nnmpc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -62,7 +63,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dst, (size_t)nseg * n)); CK(hipMemset(dst, 0, (size_t)nseg * n));
   CK(hipMalloc(&dHf, hf.size() * 2)); CK(hipMemcpy(dHf, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
   d.xunc = dx; d.lb = dlb; d.ub = dub; d.st = dst;
-  PredArgs pa; pa.Hf = dHf; pa.iters = iters; pa.adaptive = 0; pa.itsum = nullptr;
+  PredArgs pa; pa.Hf = dHf; pa.iters = iters; pa.adaptive = 0; pa.fac10 = 3; pa.itsum = nullptr;
   { double t = 1.0; for (int k = 0; k < PRED_MAXIT; ++k) { const double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t * t)); pa.beta[k] = k < iters ? (float)((t - 1.0) / tn) : 0.f; t = tn; } }
   CK(hipFuncSetAttribute((const void*)asm_predict_k<NTm, PTm>, hipFuncAttributeMaxDynamicSharedMemorySize, pred_lds_bytes<NTm, PTm>(nu)));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -78,21 +79,35 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(st.data(), dst, st.size(), hipMemcpyDeviceToHost));
   // host emulation on a few problems
   long diff = 0, tot = 0, act = 0;
-  const int ncheck = std::min(nseg, 48);
-  for (int c = 0; c < ncheck; ++c) {
-    const int p = c * (nseg / ncheck);
-    std::vector<float> xu(W), mu(W, 0.f), y(W, 0.f), x(W);
-    for (int j = 0; j < W; ++j) { float f = (float)xunc[(size_t)p * np + j]; _Float16 h = (_Float16)f; xu[j] = (float)h; }
+  // (whole workgroups: the momentum restart is decided over the 16 PT problems of a workgroup)
+  const int MRm = 16 * PTm, nwg = (nseg + MRm - 1) / MRm, ncheck = std::min(nwg, 3) * MRm;
+  for (int cw = 0; cw < std::min(nwg, 3); ++cw) {
+    const int g = cw == 0 ? 0 : (cw == 1 ? nwg / 2 : nwg - 1);
+    std::vector<float> xu((size_t)MRm * W), mu((size_t)MRm * W, 0.f), y((size_t)MRm * W, 0.f), x(W);
+    for (int q = 0; q < MRm; ++q) {
+      const int p = std::min(g * MRm + q, nseg - 1);
+      for (int j = 0; j < W; ++j) { float f = (float)xunc[(size_t)p * np + j]; _Float16 h = (_Float16)f; xu[(size_t)q * W + j] = (float)h; }
+    }
+    int kb = 0; double rs = 0.0;
     for (int it = 0; it < iters; ++it) {
-      for (int j = 0; j < W; ++j) { double s = 0; for (int k = 0; k < W; ++k) s += (double)bff(hb[(size_t)j * W + k]) * (double)y[k]; x[j] = xu[j] - (float)s; }
-      for (int j = 0; j < W; ++j) {
-        const float wv = y[j] + x[j];
-        const float lo = (float)lb[(size_t)p * nu + j % nu], hi = (float)ub[(size_t)p * nu + j % nu];
-        const float mun = wv - fminf(fmaxf(wv, lo), hi);
-        const float yn = fmaf(pa.beta[it], mun - mu[j], mun);
-        y[j] = bff(bfh(yn));
-        if (it + 1 == iters) { const int sref = mun > 0.f ? 1 : (mun < 0.f ? 2 : 0); diff += sref != st[(size_t)p * n + j]; act += sref != 0; ++tot; }
-        mu[j] = bff(bfh(mun));
+      if (it > 0) kb = rs > 0.0 ? 0 : kb + 1;
+      rs = 0.0;
+      for (int q = 0; q < MRm; ++q) {
+        const int p = std::min(g * MRm + q, nseg - 1);
+        float* yq = &y[(size_t)q * W]; float* mq = &mu[(size_t)q * W];
+        for (int j = 0; j < W; ++j) { double s = 0; for (int k = 0; k < W; ++k) s += (double)bff(hb[(size_t)j * W + k]) * (double)yq[k]; x[j] = xu[(size_t)q * W + j] - (float)s; }
+        for (int j = 0; j < W; ++j) {
+          const float wv = yq[j] + x[j];
+          const float lo = (float)lb[(size_t)p * nu + j % nu], hi = (float)ub[(size_t)p * nu + j % nu];
+          const float mun = wv - fminf(fmaxf(wv, lo), hi);
+          const float dn = mun - mq[j];
+          const float yn = fmaf(pa.beta[kb], dn, mun);
+          rs += (double)((yq[j] - mun) * dn);
+          x[j] = bff(bfh(yn));                                   // (y of the next iteration: the products above are done)
+          if (it + 1 == iters && g * MRm + q < nseg) { const int sref = mun > 0.f ? 1 : (mun < 0.f ? 2 : 0); diff += sref != st[(size_t)p * n + j]; act += sref != 0; ++tot; }
+          mq[j] = bff(bfh(mun));
+        }
+        for (int j = 0; j < W; ++j) yq[j] = x[j];
       }
     }
   }
