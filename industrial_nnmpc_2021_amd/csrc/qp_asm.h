@@ -28,6 +28,15 @@
 #include <stdint.h>
 #include <type_traits>
 
+// Translation units.  The kernels of this header are compiled into qp_solver.o; the workgroup kernels of qp_wg.h -- minutes of
+// compile time each -- into one object per kernel (qp_wg_kernels.hip with -DASM_WG_TU=0..4, which skips the kernels here), and
+// qp_solver.hip (ASM_WG_TU = -1) only declares those.  Without ASM_WG_TU (scripts/micro) everything is defined in the including file.
+#if defined(ASM_WG_TU) && ASM_WG_TU >= 0
+#define ASM_OWN_KERNELS 0
+#else
+#define ASM_OWN_KERNELS 1
+#endif
+
 namespace nnmpc {
 
 constexpr int ASM_MLDS = 176;      // largest active set factored in LDS (11 x 11 lower 16x16 fp64 tiles)
@@ -164,6 +173,7 @@ __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1)
 
 // x_unc -> first active-set estimate.  One WAVE per problem, four per workgroup (a workgroup of 256 threads per problem was
 // launch-bound: 100 000 workgroups for 5 KB each).
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256) void asm_init_k(AsmDev d, int nrows) {
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(256) void asm_init_k(AsmDev d, int nrows) {
     d.hi[p] = max(wi, d.guess ? 0 : d.pred_w);           // (a predicted set may hold bounds anywhere in the predictor's window)
   }
 }
+#endif
 
 // Round stage 0a: ordered list of the active indices of every running problem and its length.
 // (one workgroup; returns the size of the set to all threads; wsum: 4 ints of LDS)
@@ -291,6 +302,7 @@ __device__ __forceinline__ int asm_count_wave(const AsmDev& d, int p, int hi_p) 
   }
   return m;
 }
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= d.nseg || d.state[p] != ASM_RUN) return;
@@ -306,6 +318,7 @@ __global__ __launch_bounds__(256) void asm_count_k(AsmDev d) {
     if (m > d.max_active) d.state[p] = ASM_FALLBACK;
   }
 }
+#endif
 
 // Round stage 0b: the running problems get the rows 0..nrun-1 of LAM / XH (the GEMM covers only those)
 // and a place in the list of their size class -- by exclusive scans over the problems (chunks of 1024 per
@@ -338,6 +351,7 @@ __host__ __device__ inline int asm_kgroup_bound_of(int g, int kref, int nu) {   
 }
 __device__ __forceinline__ int asm_kgroup(const AsmDev& d, int kl) { return asm_kgroup_of(kl, d.kref, d.nu); }
 __device__ __forceinline__ int asm_kgroup_bound(const AsmDev& d, int g) { return asm_kgroup_bound_of(g, d.kref, d.nu); }
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   __shared__ int wtot[ASM_NSCAN][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -384,6 +398,8 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
     d.ctot[(size_t)blockIdx.x * ASM_NSCAN + tid] = t;
   }
 }
+#endif
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   __shared__ int base[ASM_NSCAN], total[ASM_NSCAN];
   const int tid = threadIdx.x;
@@ -425,6 +441,7 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   if (col == 0) d.biglist[pos] = p;
   else d.binlist[(size_t)(col - 1) * d.nseg + pos] = p;
 }
+#endif
 
 // Workgroup-per-problem variant (the first implementation; the solver uses it for the rare sets beyond 176
 // bounds, BIG = 1): r_A = x_unc,A - b_A, S = H_AA as 16 x 16 fp64 tiles, blocked right-looking Cholesky:
@@ -573,6 +590,7 @@ __device__ __forceinline__ int asm_tile_solve(const AsmDev& d, int p, int m, con
   return 0;
 }
 
+#if ASM_OWN_KERNELS
 template <int BIG>
 __global__ __launch_bounds__(256, 4) void asm_lambda_tile_k(AsmDev d, int bin) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -595,6 +613,7 @@ __global__ __launch_bounds__(256, 4) void asm_lambda_tile_k(AsmDev d, int bin) {
     for (int i = tid; i < m; i += 256) lrow[idx[i]] = rA[i];   // the rest of the row is zero (asm_update_k)
   }
 }
+#endif
 
 // ---- register-resident version, one instantiation per number MB of 16-blocks: ONE WAVE PER PROBLEM,
 // no workgroup barriers, straight-line code.
@@ -1236,6 +1255,7 @@ __device__ __forceinline__ int asm_tile_solve32(const AsmDev& d, int p, int m, c
 }
 
 constexpr int ASM_TILE32_LDS = (ASM_BIG32 + ASM_TS + (ASM_BIG32 / 16) * (ASM_BIG32 / 16 + 1) / 2 * ASM_TS) * 4;
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(512, 1) void asm_lambda_tile32_k(AsmDev d) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
   __shared__ int s_bad;
@@ -1258,11 +1278,13 @@ __global__ __launch_bounds__(512, 1) void asm_lambda_tile32_k(AsmDev d) {
     for (int i = tid; i < m; i += 512) lrow[idx[i]] = rA[i];
   }
 }
+#endif
 
 // All register-resident fp64 size classes 0..5 in ONE launch (their workgroups are independent; separate
 // launches would serialise six tails): workgroup w walks the classes from the largest down and takes
 // four problems of the class its index falls into.  Grid: sum_b ceil(count_b / 4).
 constexpr int ASM_REG_LDS = (4 * asm_rw<double>(ASM_NREG + 3) + ASM_TS) * 8;  // bytes of dynamic LDS (largest class) + the identity tile
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
   int w = blockIdx.x;
 #define ASM_REG_CLASS(B)                                                   \
@@ -1275,8 +1297,10 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg_k(AsmDev d) {
 #undef ASM_REG_CLASS
   static_assert(ASM_NREG == 6, "one ASM_REG_CLASS line per register-resident size class");
 }
+#endif
 // The 10- and 11-block classes (145..176 bounds): same code, two waves (problems) per workgroup.
 constexpr int ASM_REG2_LDS = (2 * asm_rw<double>(11) + ASM_TS) * 8;
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(128, 1) void asm_lambda_reg2_k(AsmDev d) {
   int w = blockIdx.x;
   {
@@ -1287,8 +1311,10 @@ __global__ __launch_bounds__(128, 1) void asm_lambda_reg2_k(AsmDev d) {
   asm_lambda_reg<double, 10, 2>(d, 6, w);
   static_assert(ASM_NBIN == 8 && ASM_MLDS == 176, "classes 6 and 7 are the 10- and 11-block sets");
 }
+#endif
 // The f32 rounds of classes 0..5: two workgroups per CU (two waves per SIMD).
 constexpr int ASM_REG32_LDS = (4 * asm_rw<float>(ASM_NREG + 3) + ASM_TS) * 4;
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256, 2) void asm_lambda_reg32_k(AsmDev d) {
   int w = blockIdx.x;
 #define ASM_REG_CLASS(B)                                                            \
@@ -1300,9 +1326,11 @@ __global__ __launch_bounds__(256, 2) void asm_lambda_reg32_k(AsmDev d) {
   ASM_REG_CLASS(5) ASM_REG_CLASS(4) ASM_REG_CLASS(3) ASM_REG_CLASS(2) ASM_REG_CLASS(1) ASM_REG_CLASS(0)
 #undef ASM_REG_CLASS
 }
+#endif
 
 // ... and of classes 6, 7: four waves per workgroup, one workgroup per CU (LDS).
 constexpr int ASM_REG32B_LDS = (4 * asm_rw<float>(11) + ASM_TS) * 4;
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256, 1) void asm_lambda_reg32b_k(AsmDev d) {
   int w = blockIdx.x;
   {
@@ -1312,6 +1340,7 @@ __global__ __launch_bounds__(256, 1) void asm_lambda_reg32b_k(AsmDev d) {
   }
   asm_lambda_reg<float, 10, 4>(d, ASM_NBIN + 6, w);
 }
+#endif
 
 }  // namespace nnmpc
 #ifndef ASM_NO_WG_KERNELS             // (scripts/micro/predict_micro.hip: the workgroup kernels are minutes of compile time)
@@ -1326,6 +1355,7 @@ namespace nnmpc {
 // so |stationarity residual on the free set| <= e1max |x0|_1 + e2max |lam|_1 =: bnd, and the
 // multiplier signs are certain when every |lam_a| > bnd.  Otherwise (ASM_DONE) the full check
 // with P itself (asm_certify_k) decides.
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE per problem: the window is a few hundred columns
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1444,12 +1474,14 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
     } else if (rd >= d.max_rounds) d.state[p] = ASM_FALLBACK;
   }
 }
+#endif
 
 // Full-width check of the problems that settled inside the window (xhw = lamw * H over all columns):
 // a bound violated beyond the window joins the set and the problem runs on; otherwise it is finished
 // exactly like in asm_update_k.  Runs at the start of a round, before asm_count_k.
 // One WAVE per row of LAM (four per workgroup; 256 threads and three barriers per problem were launch and barrier latency:
 // 0.44 ms for the 83 000 problems of the round most sets settle in).
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
   // fused_c0 >= 0: the columns [fused_c0, n) were checked and written by asm_wide_gemm_k (qp_wide.h), which raised
   // wflag[p] for a violated bound; this kernel does the columns inside the window, the multiplier statistics and the
@@ -1535,6 +1567,7 @@ __global__ __launch_bounds__(256) void asm_wide_k(AsmDev d, int fused_c0) {
     }
   }
 }
+#endif
 
 // ---- the tail: when only a few problems are still running, a round of eight launches and a host read-back is all
 // latency.  asm_tail_k finishes them on the device: one workgroup per problem loops count -> fp64 solve (tiles in its
@@ -1636,10 +1669,12 @@ __device__ __forceinline__ void asm_bwd(const double* Ld, double* v, int m, int 
   else asm_bwd_t<3>(Ld, v, m, lane);
 }
 
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256) void asm_taillist_k(AsmDev d) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p < d.nseg && d.state[p] == ASM_RUN) d.biglist[atomicAdd(&d.counters[ASM_CNT_TAIL], 1)] = p;   // a few hundred at most
 }
+#endif
 // Iterations of the block-exchange phase refactor the set from scratch (asm_tile_solve, as in the round kernels).  Once a
 // problem is down to SINGLE exchanges -- where the stragglers of an ill-conditioned plant spend hundreds of iterations --
 // the set changes by one index per iteration: the kernel then keeps a dense Cholesky factor in LDS and appends a row
@@ -1652,6 +1687,7 @@ __device__ unsigned long long asm_tail_prof[8];            // diagnostics build 
 #else
 #define ASM_TP(i) do { } while (0)
 #endif
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ int s_bad, wsum[4], s_i[4], s_n[4], s_m, s_fast;
@@ -2063,10 +2099,12 @@ __global__ __launch_bounds__(256) void asm_tail_k(AsmDev d, int budget) {
   }
   if (tid == 0) { d.state[p] = ASM_FALLBACK; d.rounds[p] = rounds; }
 }
+#endif
 
 // Independent fp64 certification with P itself (px = x P):  stationarity on the free set,
 // multiplier signs on the active set, feasibility; active-set bits and status of finished problems
 // (u itself was written by asm_update_k / asm_wide_k).
+#if ASM_OWN_KERNELS
 __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min) {
   __shared__ int cnt[4];
   __shared__ double gq[4];
@@ -2147,8 +2185,10 @@ __global__ __launch_bounds__(256) void asm_certify_k(AsmDev d, double gscale_min
     if (d.iters_out) { d.iters_out[2 * p] = 0; d.iters_out[2 * p + 1] = 0; }   // no PDIP iterations, no n^3 factorisations
   }
 }
+#endif
 
 // ---- gather / scatter of the problems handed to the PDIP fallback
+#if ASM_OWN_KERNELS
 __global__ void asm_gather_k(double* x0c, double* lbc, double* ubc, const double* x0, const double* lb,
                              const double* ub, const int* list, int cnt, int n_aug, int nu) {
   const int i = blockIdx.x;
@@ -2160,6 +2200,8 @@ __global__ void asm_gather_k(double* x0c, double* lbc, double* ubc, const double
     ubc[(size_t)i * nu + k] = ub[(size_t)p * nu + k];
   }
 }
+#endif
+#if ASM_OWN_KERNELS
 __global__ void asm_gather_guess_k(unsigned char* guess, const unsigned char* st, const int* state, const int* list, int cnt, int n) {
   const int i = blockIdx.x;
   if (i >= cnt) return;
@@ -2167,6 +2209,8 @@ __global__ void asm_gather_guess_k(unsigned char* guess, const unsigned char* st
   const bool settled = state[p] == ASM_DONE;                 // finished here, rejected by the check with P
   for (int k = threadIdx.x; k < n; k += blockDim.x) guess[(size_t)i * n + k] = settled ? st[(size_t)p * n + k] : (unsigned char)255;
 }
+#endif
+#if ASM_OWN_KERNELS
 __global__ void asm_scatter_k(double* u, uint32_t* act, int* status, int* iters, const double* uc,
                               const uint32_t* actc, const int* stc, const int* itc, const int* list, int cnt,
                               int n, int words, int ldu, int nout) {
@@ -2180,5 +2224,6 @@ __global__ void asm_scatter_k(double* u, uint32_t* act, int* status, int* iters,
     if (iters) { iters[2 * p] = itc[2 * i]; iters[2 * p + 1] = itc[2 * i + 1]; }
   }
 }
+#endif
 
 }  // namespace nnmpc

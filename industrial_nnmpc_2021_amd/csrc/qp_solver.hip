@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdlib>
 #include "../../include/nnmpc.h"
+#define ASM_WG_TU (-1)              // the workgroup kernels of qp_wg.h are compiled in qp_wg_kernels.hip: declarations only here
 #include "chol_kernels.h"
 #include "gemm_kernels.h"
 #include "qp_asm.h"
@@ -1283,7 +1284,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       }
     }
     if (nrun == 0) break;
-    if (nrun <= std::min(h->asm_pool, 256) && (rounds >= (a.pred_w ? 2 : 6) || small)) {
+    static const int tail_max = getenv("NNMPC_TAIL_MAX") ? atoi(getenv("NNMPC_TAIL_MAX")) : 256;   // (the variable: diagnostics)
+    if (nrun <= std::min(h->asm_pool, tail_max) && (rounds >= (a.pred_w ? 2 : 6) || small)) {
       // the tail: a handful of stragglers (the bulk settles in 5-8 rounds) -- finish them on the device (asm_tail_k)
       // instead of paying eight launches and a read-back per round for them.  From round 6 on -- from round 2 when the first sets
       // were predicted (qp_predict.h: the bulk then settles in rounds 1-2, and rounds 3-4 were 0.9 ms for 130 problems) -- (12 before: at 100 000
@@ -1604,7 +1606,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
   A_(d.slot_prob, S); A_(d.age, S); A_(d.next_prob, 1);
   // workgroups of the large-set kernel in flight (each with its tile slab in HBM / L2): four per CU for bulk batches --
   // the kernel is a latency chain (barriers, tiles in global memory), occupancy is what hides it
-  h->asm_pool = h->seg_max >= 4096 ? 1024 : 256;
+  h->asm_pool = h->seg_max >= 4096 ? (getenv("NNMPC_TAIL_MAX") && atoi(getenv("NNMPC_TAIL_MAX")) > 1024 ? 2048 : 1024) : 256;
   A_(h->H64, (size_t)np * np); A_(h->Kunc64, (size_t)np * ka); A_(h->H32, (size_t)np * np);
   A_(h->asm_xunc, G * np); A_(h->asm_x, G * np); A_(h->asm_lam, G * np); A_(h->asm_xh, G * np);
   A_(h->asm_xhw, (G + 256) * np); A_(h->asm_rowprob, G + 256); A_(h->asm_wflag, G); A_(h->asm_wmark, G);

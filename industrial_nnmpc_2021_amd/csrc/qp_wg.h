@@ -436,6 +436,11 @@ __device__ __forceinline__ void asm_lambda_wg(const AsmDev& d, int p, int m) {
   }
 }
 
+#if defined(ASM_WG_TU)
+#define ASM_WG_DEF(n) (ASM_WG_TU == (n))        // one kernel per translation unit (see qp_asm.h); -1: declarations only
+#else
+#define ASM_WG_DEF(n) 1
+#endif
 template <class T>
 __device__ __forceinline__ void asm_lambda_wg_any(const AsmDev& d, int p) {
   const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
@@ -462,16 +467,25 @@ __device__ __forceinline__ void asm_lambda_wg_any(const AsmDev& d, int p) {
 // microsecond at 192 / 224 / 256 bounds: f32 11.8 / 8.6 / 6.4 here against 2.9 / 2.2 / 1.65 of asm_lambda_tile32_k; fp64
 // 4.2 / 2.8 / 2.3.  Eight waves per problem -- half the tiles per wave, no spills at 16 blocks -- were SLOWER: 4.5 at 256
 // bounds in f32, one workgroup per CU and twice the barrier traffic.)
+#if ASM_WG_DEF(0)
 __global__ __launch_bounds__(256, 2) void asm_lambda_wg32_k(AsmDev d) {
   if ((int)blockIdx.x < d.counters[ASM_CNT_BIG32]) asm_lambda_wg_any<float>(d, d.binlist[(size_t)ASM_NLIST * d.nseg + blockIdx.x]);
 }
+#else
+__global__ void asm_lambda_wg32_k(AsmDev d);
+#endif
+#if ASM_WG_DEF(1)
 __global__ __launch_bounds__(256, 1) void asm_lambda_wg64_k(AsmDev d) {
   if ((int)blockIdx.x < d.counters[ASM_CNT_BIG64]) asm_lambda_wg_any<double>(d, d.binlist[(size_t)(ASM_NLIST + 1) * d.nseg + blockIdx.x]);
 }
+#else
+__global__ void asm_lambda_wg64_k(AsmDev d);
+#endif
 
 // f32 rounds of the sets of 257 .. 384 bounds (list ASM_NLIST + 2): EIGHT waves per problem, one workgroup per CU.  Until round 4
 // these sets ran every round -- f32 or not -- in the fp64 L2-slab kernel (1.9 us per solve at 290 bounds); an f32 result only moves
 // the set, and the tiles of 17 .. 24 blocks fit the registers of eight waves in f32 (153 .. 300 tiles: at most 48 per wave).
+#if ASM_WG_DEF(2)
 __global__ __launch_bounds__(512, 1) void asm_lambda_wg32b_k(AsmDev d) {
   if ((int)blockIdx.x >= d.counters[ASM_CNT_BIG32B]) return;
   const int p = d.binlist[(size_t)(ASM_NLIST + 2) * d.nseg + blockIdx.x];
@@ -488,9 +502,13 @@ __global__ __launch_bounds__(512, 1) void asm_lambda_wg32b_k(AsmDev d) {
     default: asm_lambda_wg<float, 17, 8>(d, p, m); break;
   }
 }
+#else
+__global__ void asm_lambda_wg32b_k(AsmDev d);
+#endif
 
 // fp64 solves of the sets of 257 .. 384 bounds (list ASM_NLIST + 3): the same eight-wave f32 factorisation, refined to fp64
 // residuals (REFINE above).  Replaces the fp64 L2-slab kernel there (1.9 us per solve at 290 bounds).
+#if ASM_WG_DEF(3)
 __global__ __launch_bounds__(512, 1) void asm_lambda_wg64r_k(AsmDev d) {
   if ((int)blockIdx.x >= d.counters[ASM_CNT_BIG64R]) return;
   const int p = d.binlist[(size_t)(ASM_NLIST + 3) * d.nseg + blockIdx.x];
@@ -507,6 +525,9 @@ __global__ __launch_bounds__(512, 1) void asm_lambda_wg64r_k(AsmDev d) {
     default: asm_lambda_wg<float, 17, 8, true>(d, p, m); break;
   }
 }
+#else
+__global__ void asm_lambda_wg64r_k(AsmDev d);
+#endif
 
 // (The same for the sets of 177 .. 256 bounds -- four waves, f32 tiles, two workgroups per CU, refined -- is no faster than the fp64
 // register kernel asm_lambda_wg64_k there: 4.4 / 3.0 / 2.5 against 4.3 / 3.3 / 2.3 problems per microsecond at 192 / 224 / 256
@@ -548,6 +569,10 @@ __device__ __forceinline__ void asm_lambda_wg2(const AsmDev& d, int c7, int c6) 
 #ifdef ASM_WG_MICRO
 __global__ __launch_bounds__(128, 4) void asm_lambda_wg32s_k(AsmDev d) { asm_lambda_wg2<float>(d, ASM_CNT_F32 + 7, ASM_CNT_F32 + 6); }
 #endif
+#if ASM_WG_DEF(4)
 __global__ __launch_bounds__(128, 2) void asm_lambda_wg64s_k(AsmDev d) { asm_lambda_wg2<double>(d, 4 + 7, 4 + 6); }
+#else
+__global__ void asm_lambda_wg64s_k(AsmDev d);
+#endif
 
 }  // namespace nnmpc

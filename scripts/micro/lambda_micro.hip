@@ -21,6 +21,7 @@ extern "C" __global__ __launch_bounds__(256, PROBE_OCC) void probe_k(AsmDev d) {
 }
 #endif
 
+#ifndef ASM_NO_WG_KERNELS
 // variants 10 / 11: the workgroup kernels of qp_wg.h with EIGHT waves per problem (fp64 / f32), 12 .. 16 blocks
 template <class T> __device__ __forceinline__ void wg8_any(const AsmDev& d, int p) {
   const int m = __builtin_amdgcn_readfirstlane(d.mg[p]);
@@ -34,13 +35,16 @@ template <class T> __device__ __forceinline__ void wg8_any(const AsmDev& d, int 
 }
 __global__ __launch_bounds__(512, 1) void wg64_8_k(AsmDev d) { if ((int)blockIdx.x < d.counters[ASM_CNT_BIG64]) wg8_any<double>(d, d.binlist[(size_t)(ASM_NLIST + 1) * d.nseg + blockIdx.x]); }
 __global__ __launch_bounds__(512, 2) void wg32_8_k(AsmDev d) { if ((int)blockIdx.x < d.counters[ASM_CNT_BIG32]) wg8_any<float>(d, d.binlist[(size_t)ASM_NLIST * d.nseg + blockIdx.x]); }
+#endif
 
 int main(int argc, char** argv) {
   const int m = argc > 1 ? atoi(argv[1]) : 112;
   const int nseg = argc > 2 ? atoi(argv[2]) : 14336;
   const int variant = argc > 3 ? atoi(argv[3]) : 0;      // 0 tile kernel, 1 register kernel (fp64), 2 register kernel (f32)
   const int n = 512, np = 512, nu = 32, max_active = 768;
-  const int win = argc > 4 ? atoi(argv[4]) : 416;         // the active indices are drawn from [0, win): win = m makes them contiguous
+  const int win0 = argc > 4 ? atoi(argv[4]) : 416;        // the active indices are drawn from [0, win): win = m makes them contiguous
+  const int win = win0 > 0 ? win0 : 512;                   // win < 0: -win inputs saturated over the first steps (indices step * nu + input: the solver's pattern)
+  const int gperm = argc > 5 ? atoi(argv[5]) : 0;          // 1: the list in input-major order (same set, another pivot order)
   std::mt19937_64 rng(1);
   std::normal_distribution<double> g(0.0, 1.0);
   std::vector<double> G((size_t)n * n), H((size_t)n * n);
@@ -59,7 +63,15 @@ int main(int argc, char** argv) {
   for (int p = 0; p < nseg; ++p) {
     for (int i = 0; i < win; ++i) perm[i] = i;
     std::shuffle(perm.begin(), perm.end(), rng);
+    if (win0 < 0) {
+      const int k = -win0;
+      std::vector<int> inp(nu);
+      for (int i = 0; i < nu; ++i) inp[i] = i;
+      std::shuffle(inp.begin(), inp.end(), rng);           // the k saturated inputs
+      for (int i = 0; i < m; ++i) perm[i] = (i / k) * nu + inp[i % k];
+    }
     std::sort(perm.begin(), perm.begin() + m);
+    if (gperm) std::stable_sort(perm.begin(), perm.begin() + m, [&](int a, int b) { return a % nu < b % nu; });
     for (int i = 0; i < m; ++i) { idx[(size_t)p * max_active + i] = perm[i]; st[(size_t)p * n + perm[i]] = 1 + (perm[i] & 1); }
     list[p] = p;
   }
@@ -95,7 +107,7 @@ int main(int argc, char** argv) {
     d.H32 = dH32;
   }
   float* dlam32; CK(hipMalloc(&dlam32, xunc.size() * 4)); CK(hipMemset(dlam32, 0, xunc.size() * 4)); d.lam32 = dlam32;
-  unsigned char* drowk; CK(hipMalloc(&drowk, nseg)); CK(hipMemset(drowk, 0, nseg)); d.rowk = drowk;
+  unsigned char* drowk; CK(hipMalloc(&drowk, nseg)); CK(hipMemset(drowk, 1, nseg)); d.rowk = drowk;
   int* drow; CK(hipMalloc(&drow, nseg * 4)); CK(hipMemcpy(drow, list.data(), nseg * 4, hipMemcpyHostToDevice)); d.row = drow;
   const int mbc = asm_bin_cap(bin) / 16;
   const int lds_tile = (asm_bin_cap(bin) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
@@ -108,6 +120,7 @@ int main(int argc, char** argv) {
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     CK(hipEventRecord(e0, 0));
+#ifndef ASM_NO_WG_KERNELS
     if (variant == 7) hipLaunchKernelGGL(asm_lambda_wg32s_k, dim3(nseg), dim3(128), asm_wg_lds_bytes<float>(), 0, d);
     else if (variant == 8) hipLaunchKernelGGL(asm_lambda_wg64s_k, dim3(nseg), dim3(128), asm_wg_lds_bytes<double>(), 0, d);
     else if (variant == 5) hipLaunchKernelGGL(asm_lambda_wg32_k, dim3(nseg), dim3(256), asm_wg_lds_bytes<float>(), 0, d);
@@ -117,7 +130,9 @@ int main(int argc, char** argv) {
     else if (variant == 12) hipLaunchKernelGGL(asm_lambda_wg32b_k, dim3(nseg), dim3(512), (asm_wg_lds_bytes<float, ASM_WG_MB8>()), 0, d);
     else if (variant == 10) hipLaunchKernelGGL(wg64_8_k, dim3(nseg), dim3(512), asm_wg_lds_bytes<double>(), 0, d);
     else if (variant == 11) hipLaunchKernelGGL(wg32_8_k, dim3(nseg), dim3(512), asm_wg_lds_bytes<float>(), 0, d);
-    else if (variant == 4) {                                  // f32 LDS-tile workgroup kernel (177..256 bounds)
+    else
+#endif
+    if (variant == 4) {                                  // f32 LDS-tile workgroup kernel (177..256 bounds)
       static bool once4 = false;
       if (!once4) { CK(hipFuncSetAttribute((const void*)asm_lambda_tile32_k, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_TILE32_LDS)); once4 = true; }
       hipLaunchKernelGGL(asm_lambda_tile32_k, dim3(std::min(nseg, 4096)), dim3(512), ASM_TILE32_LDS, 0, d);
