@@ -28,7 +28,7 @@ step pmc_hbm bash -c "timeout -k 10 400 bash scripts/pmc_hbm.sh cdu_b100000 --st
 step pmc_hbm_nn bash -c "timeout -k 10 300 bash scripts/pmc_hbm.sh nn_b1048576 --workload nn --steps 1 --warmup 1"; cp profiles/pmc_hbm_nn_b1048576.json gpurun_out/ 2>/dev/null
 step pmc_hbm_cstrs bash -c "timeout -k 10 300 bash scripts/pmc_hbm.sh cstrs_b10000 --workload cstrs --batch 10000 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io"; cp profiles/pmc_hbm_cstrs_b10000.json gpurun_out/ 2>/dev/null
 step pmc_sq bash -c "timeout -k 10 400 bash scripts/pmc_sq.sh ${T} --steps 1 --warmup 2 --no-extras --no-cpu-baseline --no-parity --no-pdip --no-host-io"; cp profiles/${T}_pmc_sq.json gpurun_out/
-step bench bash -c "timeout -k 10 700 python bench.py > gpurun_out/${T}_cdu_b100000_bench.json 2> gpurun_out/${T}_bench.err"; tail -c 300 gpurun_out/${T}_bench.err
+step bench bash -c "NNMPC_BENCH_DETAIL=gpurun_out/${T}_bench_detail.json timeout -k 10 700 python bench.py > gpurun_out/${T}_cdu_b100000_bench.json 2> gpurun_out/${T}_bench.err"; tail -c 300 gpurun_out/${T}_bench.err
 fi
 rm -rf gpurun_out/${T}_kt gpurun_out/pmc_hbm_cdu_b100000 gpurun_out/pmc_hbm_nn_b1048576 gpurun_out/pmc_hbm_cstrs_b10000 gpurun_out/pmc_${T} gpurun_out/${T}_cdu_b100000_kernel_trace.csv
 cat gpurun_out/${T}_steps_${WHAT}.txt
