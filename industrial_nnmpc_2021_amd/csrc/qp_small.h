@@ -19,6 +19,8 @@
 //     asm_small_k<7, 1, 8>   sets of up to 112 bounds: the problems the first instance handed back (one in twenty of that batch); a
 //                            four-block solve up to 64 bounds, a seven-block one (first five block columns' tiles in LDS, identity
 //                            padding for any size) beyond
+//     asm_small_k<9, 1, 8>   sets of up to 144 bounds: what outgrew the second (rare -- one problem per batch or none --, but the lock-step
+//                            rounds and the device tail behind them cost that batch a millisecond)
 // A problem whose set outgrows an instance, or that is still moving after `budget` iterations, is handed back as it stands
 // (bound states, exchange-rule memory, iteration count): it stays ASM_RUN and the next instance, then the lock-step rounds / the
 // device tail carry on.  Same arithmetic (fp64 everywhere), same tests, same certificate: the answers are the ones the rounds give.

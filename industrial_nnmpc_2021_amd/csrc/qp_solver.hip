@@ -1151,6 +1151,10 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     static const int g0 = getenv("NNMPC_SMALL_GRACE") ? atoi(getenv("NNMPC_SMALL_GRACE")) : ASM_SM_GRACE;
     hipLaunchKernelGGL((asm_small_k<2, 3, 4>), dim3(nprob), dim3(64), asm_small_lds_bytes(2, h->n, h->nu), s, a, a.max_rounds, g0);
     hipLaunchKernelGGL((asm_small_k<7, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(7, h->n, h->nu), s, a, a.max_rounds, g0);
+    // ... and the sets that outgrow its 112 bounds (one problem in two of three 10 000-problem batches of the CSTRs-size plant: handed
+    // to the lock-step machinery it cost a round of bookkeeping launches, a read-back and 30 more iterations in the device tail -- 2.7 -
+    // 3.1 ms per step against 1.4 without such a problem) carry on in a nine-block instance; a wave whose problem is finished exits at once
+    hipLaunchKernelGGL((asm_small_k<9, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(9, h->n, h->nu), s, a, a.max_rounds, g0);
     h->stats.asm_rounds += 1;
     h->stats.asm_small_passes += 1;
     static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations and set sizes per problem
@@ -1561,6 +1565,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k<WIDE_LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k<WIDE_FAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_t_k, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_small_k<9, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, asm_small_lds_bytes(9, ASM_SM_NMAX, 64));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_kdyn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
