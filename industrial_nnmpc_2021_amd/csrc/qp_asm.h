@@ -852,6 +852,7 @@ __device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* i
   const int li = lane & 15, lq = lane >> 4;
   auto slot = [](int I, int J) { return J * (MB - 1) - J * (J - 1) / 2 + I - J - 1; };   // tile (I,J), J < NL, I > J
   (void)wg; (void)wave;
+  ASM_STAMP(60);                                           // (right-hand side and index list in LDS)
   // ---- gather: t(I,J)[r] = -S[16 I + li][16 J + kr(lq, r)], read as Pinv[row of (J, lq, r)][col of (I, li)].
   // The not yet factored tiles hold MINUS the Schur complement, so the trailing update is a plain
   // accumulation (the MFMAs have no negate modifier; a VALU negation would cost a pass over the operands).

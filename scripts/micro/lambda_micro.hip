@@ -181,7 +181,7 @@ int main(int argc, char** argv) {
   {
     unsigned long long st_[64];
     CK(hipMemcpyFromSymbol(st_, HIP_SYMBOL(asm_stamp_buf), sizeof st_));
-    printf("stamps (cycles since wave start): rhs+gather issued %llu, first tile ready %llu, diag0 %llu\n", st_[1] - st_[0], st_[2] - st_[0], st_[3] - st_[2]);
+    printf("stamps (cycles since wave start): rhs in LDS %llu, rhs+gather issued %llu, first tile ready %llu, diag0 %llu\n", st_[60] - st_[0], st_[1] - st_[0], st_[2] - st_[0], st_[3] - st_[2]);
     for (int K = 0; K < 9 && st_[4 + 3 * K]; ++K)
       printf("  column %d: start %llu  trsm-issued +%llu  trail-issued +%llu  (next column at +%llu)\n", K, st_[4 + 3 * K] - st_[0], st_[5 + 3 * K] - st_[4 + 3 * K],
              st_[6 + 3 * K] > st_[5 + 3 * K] ? st_[6 + 3 * K] - st_[5 + 3 * K] : 0ull, st_[4 + 3 * (K + 1)] > st_[4 + 3 * K] ? st_[4 + 3 * (K + 1)] - st_[4 + 3 * K] : 0ull);
