@@ -1,7 +1,8 @@
 """GPU parity tests of the one-wave-per-problem kernels of small problems (qp_small.h: asm_small_k), through the C ABI.
 
 The whole active-set iteration of a problem runs in one wave (sets of up to 32 bounds in the first instance, up to 112 in the
-second); larger sets and problems over the iteration budget are handed to the lock-step rounds / the device tail as they stand.
+second, up to 144 in the third); larger sets and problems over the iteration budget are handed to the lock-step rounds / the device
+tail as they stand.
 Checked against the fp64 oracle (oracle/qp.py) and against the same call with the kernels switched off (NNMPC_NO_SMALL=1: the
 rounds of qp_asm.h): same status, same active sets, u equal to rounding.
 """
@@ -67,8 +68,9 @@ def test_small_kernels_equal_the_rounds_and_the_oracle(monkeypatch, name, B, sx)
 
 
 def test_sets_beyond_both_instances_are_handed_on(monkeypatch):
-    """CSTRs size at a wide spread: sets of 33 .. 112 bounds pass through the second instance, larger ones are handed to the rounds /
-    the device tail with their bound states and exchange-rule memory -- every problem certified, active sets as the rounds alone find."""
+    """CSTRs size at a wide spread: sets of 33 .. 112 bounds pass through the second instance, 113 .. 144 through the third, larger
+    ones are handed to the rounds / the device tail with their bound states and exchange-rule memory -- every problem certified,
+    active sets as the rounds alone find."""
     from industrial_nnmpc_2021_amd.qp import BatchedBoxQP
     B = 2000
     P, tq, nu, N, x0, lb, ub = _problem("cstrs", B, 11, 4.0)
