@@ -57,6 +57,7 @@ constexpr int ASM_BIG32B = 384;           // largest set whose f32 rounds run in
                                           // (asm_lambda_wg32b_k, qp_wg.h); beyond, and for every fp64 solve beyond 256: the L2-slab kernel
 constexpr int ASM_CNT_BIG64R = 31;        // counters[31]: length of list ASM_NLIST + 3 (fp64 solves of sets of 257 .. 384 bounds: f32 factor + fp64 refinement)
 constexpr int ASM_CNT_BIG32B = 39;        // counters[39]: length of list ASM_NLIST + 2 (f32 rounds of sets of 257 .. 384 bounds)
+constexpr double ASM_REFINE_TOL = 1e-12;   // residual of a corrected f32 solve, relative to max |b|, that counts as an fp64 solve (asm_update_k)
 constexpr int ASM_GRACE = 10;       // rounds without a new minimum of infeasible indices before single exchanges take over
 constexpr int ASM_CNT_WIDE = 12;   // counters[13]: problems handled by the last asm_wide_k, counters[ASM_CNT_WKSUM]: the sum of their
 constexpr int ASM_CNT_WKSUM = 30;  // (last active index + 1) -- statistics, from the scans of asm_bins (no atomics)
@@ -156,6 +157,8 @@ struct AsmDev {
   const double* xhw;               // [rows] = lam * H beyond the window (shapes the fused kernels' tiles do not fit)
   int tail_gi;                     // asm_tail_k: dual active-set steps (Goldfarb-Idnani) instead of Murty's single exchanges once block exchanges stop making progress (off: measured slower, see there)
   int use_wg;                      // sets of 145 .. 256 bounds go to the four-wave register kernels (qp_wg.h); 0: the single-wave / LDS-tile / slab kernels (A/B)
+  int refine;                      // f32 rounds of sets of <= ASM_MLDS bounds get rows of LAM (fp64) and correct a result that can be final in fp64 (asm_reg_core)
+  int refine_later;                // ... from the next round on (this one may still be a plain f32 screen): a set that settles in f32 now is NOT sent to the fp64 kernel
   int early64;                     // an f32 round that moves at most this many bounds is followed by an fp64 round (0: only a settled set is)
   int* wflag;                      // [nseg] set by asm_wide_gemm_k when a bound beyond the window is violated (cleared by asm_wide_k)
   double* work;                    // [nseg][3] statistics: flops (m^3/3 + 2 m^2) and gathered bytes of the lambda kernels, flops of the f32 rounds
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(1024) void asm_bins_a_k(AsmDev d) {
   int kl = 0;
   if (run) { const int m = d.mg[p]; if (m > 0) kl = d.idxg[(size_t)p * d.max_active + m - 1]; }
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const bool r32 = (col > ASM_NBIN && col <= 1 + ASM_NLIST) || col == 3 + ASM_NLIST;   // solved in f32 this round: row of LAM32 / XH32
+  const bool r32 = (col > ASM_NBIN + (d.refine ? ASM_NBIN : 0) && col <= 1 + ASM_NLIST) || col == 3 + ASM_NLIST;   // solved in f32 this round AND not corrected: row of LAM32 / XH32
   const int rcol = run ? ASM_COL_ROW + (r32 ? ASM_NKG : 0) + asm_kgroup(d, kl) : -1;
   int myrank = 0, myrow = 0;
 #pragma unroll
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(1024) void asm_bins_b_k(AsmDev d) {
   if (!run) return;
   const int m = d.mg[p];
   const int kl = m > 0 ? d.idxg[(size_t)p * d.max_active + m - 1] : 0;
-  const bool r32 = (col > ASM_NBIN && col <= 1 + ASM_NLIST) || col == 3 + ASM_NLIST;
+  const bool r32 = (col > ASM_NBIN + (d.refine ? ASM_NBIN : 0) && col <= 1 + ASM_NLIST) || col == 3 + ASM_NLIST;
   const int c0 = ASM_COL_ROW + (r32 ? ASM_NKG : 0), g = asm_kgroup(d, kl);
   int row = d.row[p] + base[c0 + g];
   for (int gg = 0; gg < g; ++gg) row += total[c0 + gg];      // rows ordered by group
@@ -844,9 +847,22 @@ __device__ unsigned long long asm_stamp_buf[64];
 // multiplier of bound 16 I + li (every lane row holds a copy).  Returns non-zero (lam untouched) when S is not positive
 // definite in this precision.  lt: base of the LDS-resident tiles of this wave PLUS lane.  NL: block columns whose tiles live there.
 // MB >= 5 expects 16 (MB - 1) < m <= 16 MB (the size classes of the rounds) unless ANYM is set.
-template <class T, int MB, int NL = asm_nl<T>(MB), bool ANYM = false>
+// REF (the f32 instances of the rounds, do_refine): when every multiplier of the f32 solve has the sign that keeps its bound -- the
+// set may be final --, ONE correction in fp64 with the factor at hand: r = b - S lam with S gathered again from the fp64 inverse (fp64
+// FMAs, lam broadcast from LDS, the loads of two columns in flight), L L' dl = r through the tiles in the registers, lam + dl in
+// fp64 (rf.lam64; returns 2).  The error goes from cond(S) * 6e-8 to ~(cond(S) * 6e-8)^2: 1e-14 on the CDU plant, whose sets have
+// cond(S) = 11 .. 18 -- what an fp64 factorisation leaves.  It is not taken on trust: the window GEMM of the round forms S (lam + dl)
+// for everybody, and asm_update_k accepts the set only if that residual is at the fp64 floor (else the set runs again in the fp64
+// kernel).  The round that used to confirm a settled set in fp64 -- the largest launch of a step -- is this one.
+template <int MB> struct AsmRefine {
+  const double *xunc, *lb, *ub;    // of this problem: [np], [nu], [nu]
+  const unsigned char* st;         // [n]
+  const int* idx;                  // the ordered active indices (global memory)
+  double lam64[MB];                // out: multiplier of bound 16 I + li
+};
+template <class T, int MB, int NL, bool ANYM, bool REF>
 __device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* ix, T* dt, T* Yt, T* ys, const T* rv, T* lt, const T* idt,
-                                            T (&lam)[MB], int lane, int wg, int wave) {
+                                            T (&lam)[MB], int lane, int wg, int wave, AsmRefine<MB>& rf, bool do_refine) {
   using N = AsmNum<T>;
   using V4 = typename N::v4;
   const int li = lane & 15, lq = lane >> 4;
@@ -1016,23 +1032,126 @@ __device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* i
   if (bad) return 1;
   ASM_FENCE();
   // ---- backward substitution  L' lam = y
+  auto backward = [&](T (&out)[MB]) __attribute__((always_inline)) {
 #pragma unroll
-  for (int K = MB - 1; K >= 0; --K) {
-    T part = T(0);
-    T s4[4] = {T(0), T(0), T(0), T(0)};                    // (sum_I L(I,K)' lam_I)[kr(lq, r)], summed over li
-    if (K < MB - 1) {
+    for (int K = MB - 1; K >= 0; --K) {
+      T part = T(0);
+      T s4[4] = {T(0), T(0), T(0), T(0)};                  // (sum_I L(I,K)' lam_I)[kr(lq, r)], summed over li
+      if (K < MB - 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int I = K + 1; I < MB; ++I) s4[r] += (K < NL ? lt[slot(I, K) * 256 + r * 64] : C[asm_tix(I, K)][r]) * lam[I];
-      rowsum16x4<T>(s4);
+          for (int I = K + 1; I < MB; ++I) s4[r] += (K < NL ? lt[slot(I, K) * 256 + r * 64] : C[asm_tix(I, K)][r]) * out[I];
+        rowsum16x4<T>(s4);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part += C[asm_tix(K, K)][r] * (ys[16 * K + N::kr(lq, r)] - s4[r]);   // Y_K[kr(lq, r)][li] tt[kr(lq, r)]
+      out[K] = xsum4<T>(part);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  backward(lam);
+  if constexpr (REF) {
+    if (!do_refine) return 0;
+    // ---- one fp64 correction of a solve whose multipliers all keep their bounds
+    int ai[MB], sa[MB];
+    double bb[MB], bnd[MB];
+    bool wrong = false;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part += C[asm_tix(K, K)][r] * (ys[16 * K + N::kr(lq, r)] - s4[r]);   // Y_K[kr(lq, r)][li] tt[kr(lq, r)]
-    lam[K] = xsum4<T>(part);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int I = 0; I < MB; ++I) ai[I] = rf.idx[min(16 * I + li, m - 1)];        // (three rounds of unconditional loads, then the selects)
+#pragma unroll
+    for (int I = 0; I < MB; ++I) { sa[I] = rf.st[ai[I]]; bb[I] = rf.xunc[ai[I]]; }
+#pragma unroll
+    for (int I = 0; I < MB; ++I) { const int k = ai[I] % d.nu; bnd[I] = sa[I] == 1 ? rf.ub[k] : rf.lb[k]; }
+#pragma unroll
+    for (int I = 0; I < MB; ++I) {
+      const bool in = 16 * I + li < m;
+      bb[I] = in ? bb[I] - bnd[I] : 0.0;
+      const double l = (double)lam[I];
+      wrong |= in && ((sa[I] == 1 && l <= 0.0) || (sa[I] == 2 && l >= 0.0));   // asm_update_k's test: the set moves anyway
+    }
+#ifndef ASM_REFINE_ALWAYS               // (scripts/micro/lambda_micro.hip: synthetic sets, random signs)
+    if (__any(wrong)) return 0;
+#endif
+    int* ixr = reinterpret_cast<int*>(const_cast<T*>(rv));  // [16 MB] (rv's last reader was the forward substitution above)
+    double* l64 = reinterpret_cast<double*>(dt);            // [16 MB] over dt / Yt (2 * ASM_TS floats: 16 MB <= 272)
+    static_assert(16 * MB * 8 <= 2 * ASM_TS * (int)sizeof(T) || !N::F32, "lam64 does not fit the diagonal-tile buffers");
+    unsigned gco[MB];
+#pragma unroll
+    for (int I = 0; I < MB; ++I) {
+      gco[I] = (unsigned)ai[I] * 8u;
+      if (lq == 0) { ixr[16 * I + li] = ai[I]; l64[16 * I + li] = 16 * I + li < m ? (double)lam[I] : 0.0; }
+    }
+    ASM_FENCE();
+    const char* const H64 = reinterpret_cast<const char*>(d.H);
+    double acc[MB];
+#pragma unroll
+    for (int I = 0; I < MB; ++I) acc[I] = 0.0;
+    {
+      // column j = 4 jj + lq of S (entries beyond m: index repeated, lam = 0); the MB loads of TWO columns in flight (left to the
+      // compiler -- 256 registers, the tiles live -- every load was followed by s_waitcnt vmcnt(0))
+      double hv[2][MB], lj[2];
+      auto issue = [&](int jj, auto bc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value;
+        const int j = 4 * jj + lq;
+        const unsigned rowoff = (unsigned)ixr[j] * (unsigned)d.np * 8u;
+        lj[b] = l64[j];
+#pragma unroll
+        for (int I = 0; I < MB; ++I) hv[b][I] = *reinterpret_cast<const double*>(H64 + (rowoff + gco[I]));
+      };
+      issue(0, asm_ic<0>{});
+#pragma unroll 1
+      for (int jj = 0; jj < 4 * MB; jj += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue(jj + 1, asm_ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int I = 0; I < MB; ++I) acc[I] = fma(hv[0][I], lj[0], acc[I]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(min(jj + 2, 4 * MB - 1), asm_ic<0>{});         // (the last trip loads a column again: no branch in the loop)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int I = 0; I < MB; ++I) acc[I] = fma(hv[1][I], lj[1], acc[I]);
+      }
+    }
+    T rr[MB];
+#pragma unroll
+    for (int I = 0; I < MB; ++I) rr[I] = 16 * I + li < m ? (T)(bb[I] - xsum4<double>(acc[I])) : T(0);
+    // forward substitution  L y = r  (the factorisation's, without the MFMAs)
+#pragma unroll
+    for (int I = 0; I < MB; ++I) ps[I] = T(0);
+    asm_sfor<0, MB>([&](auto Kc) __attribute__((always_inline)) {
+      constexpr int K = decltype(Kc)::value;
+      const V4 Yc = C[asm_tix(K, K)];
+      const T tK = rr[K] - (K ? xsum4<T>(ps[K]) : T(0));
+      T yq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) yq[r] = Yc[r] * tK;
+      rowsum16x4<T>(yq);
+      if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ys[16 * K + N::kr(lq, r)] = yq[r];
+      }
+#pragma unroll
+      for (int I = K + 1; I < MB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ps[I] += (K < NL ? lt[slot(I, K) * 256 + r * 64] : C[asm_tix(I, K)][r]) * yq[r];
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    ASM_FENCE();
+    T dl[MB];
+    backward(dl);
+#pragma unroll
+    for (int I = 0; I < MB; ++I) rf.lam64[I] = (double)lam[I] + (double)dl[I];
+    return 2;
   }
   return 0;
+}
+template <class T, int MB, int NL = asm_nl<T>(MB), bool ANYM = false>
+__device__ __forceinline__ int asm_reg_core(const AsmDev& d, int m, const int* ix, T* dt, T* Yt, T* ys, const T* rv, T* lt, const T* idt,
+                                            T (&lam)[MB], int lane, int wg, int wave) {
+  AsmRefine<MB> none;
+  return asm_reg_core<T, MB, NL, ANYM, false>(d, m, ix, dt, Yt, ys, rv, lt, idt, lam, lane, wg, wave, none, false);
 }
 
 template <class T, int MB, int WPB>
@@ -1071,7 +1190,21 @@ __device__ __forceinline__ void asm_lambda_reg(const AsmDev& d, int list, int wg
   }
   ASM_FENCE();
   T lam[MB];
-  const int bad = asm_reg_core<T, MB>(d, m, ix, dt, Yt, ys, rv, lt, idt, lam, lane, wg, wave);
+  // f32 rounds with a row of LAM (fp64): asm_bins hands those out when d.refine is set -- a result that can be final gets its fp64 correction
+  AsmRefine<MB> rf;
+  const bool refine = N::F32 && d.rowk[p] == 0;
+  if (N::F32) { rf.xunc = d.xunc + o; rf.lb = d.lb + (size_t)p * d.nu; rf.ub = d.ub + (size_t)p * d.nu; rf.st = st; rf.idx = idx; }
+  const int bad = asm_reg_core<T, MB, asm_nl<T>(MB), false, N::F32>(d, m, ix, dt, Yt, ys, rv, lt, idt, lam, lane, wg, wave, rf, refine);
+  if (N::F32 && refine && bad != 1) {
+    if (bad == 2 && lane == 0) d.redo[p] = 2;               // corrected in fp64: asm_update_k verifies the residual and may accept the set
+    double* lrow64 = d.lam + (size_t)d.row[p] * d.np;
+#pragma unroll
+    for (int I = 0; I < MB; ++I) {
+      const int i = 16 * I + li;
+      if (lq == 0 && i < m) lrow64[idx[i]] = bad == 2 ? rf.lam64[I] : (double)lam[I];
+    }
+    return;
+  }
   if (bad) {
     // f32: S is not positive definite in this precision -- this round is void (asm_update_k skips the problem,
     // its LAM row is still zero), the next one runs in fp64.  fp64: hand the problem to the PDIP path.
@@ -1361,10 +1494,12 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= d.nseg || d.state[p] != ASM_RUN) return;
-  if (d.redo[p]) {                                           // the f32 kernel gave up on this set: nothing was computed,
+  const int rdo = d.redo[p];
+  if (rdo == 1) {                                            // the f32 kernel gave up on this set: nothing was computed,
     if (lane == 0) d.redo[p] = 0;                            // the same set runs again in fp64
     return;
   }
+  if (rdo && lane == 0) d.redo[p] = 0;                       // 2: an f32 solve with its fp64 correction (asm_reg_core): verified below
   const bool f32_phase = d.rowk[p] != 0;                     // f32 solve and GEMM: only good enough to move the set
   const size_t o = (size_t)p * d.np, orow = (size_t)d.row[p] * d.np;
   unsigned char* st = d.st + (size_t)p * d.n;
@@ -1382,6 +1517,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   const int wv = threadIdx.x >> 6;
   int chg = 0, rmax = 0x7fffffff;                            // the index a single exchange takes: the smallest infeasible one
   double l1 = 0.0, lmin = 1e300;
+  double res_r = 0.0, res_b = 0.0;                           // max |b - S lam| and max |b| over the set (rdo == 2: from the GEMM's row)
   auto scan = [&](int mode) {                                // 0: count and record, 1: apply all, 2: apply only index rmax (the smallest infeasible one)
     // (loading eight chunks of the window at once, unconditionally, before the tests -- instead of bound state, branch, then x_unc
     // and the GEMM's row per chunk -- made this kernel slower: 0.30 -> 0.53 ms per round at 100 000 problems)
@@ -1399,6 +1535,12 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
       const int a = idx[i], sa = st[a];
       const double l = f32_phase ? (double)d.lam32[orow + a] : d.lam[orow + a];
       if (mode == 0) { l1 += fabs(l); lmin = fmin(lmin, fabs(l)); }
+      if (mode == 0 && rdo == 2) {
+        const int k = a % d.nu;
+        const double b = d.xunc[o + a] - (sa == 1 ? d.ub[(size_t)p * d.nu + k] : d.lb[(size_t)p * d.nu + k]);
+        res_b = fmax(res_b, fabs(b));
+        res_r = fmax(res_r, fabs(b - d.xh[orow + a]));
+      }
       if (!((sa == 1 && l <= 0.0) || (sa == 2 && l >= 0.0))) continue;
       if (mode == 0) { if (chg < 8) { ch_r[wv][chg][lane] = (unsigned short)a; ch_s[wv][chg][lane] = 0; } ++chg; rmax = min(rmax, a); }
       else if (mode == 1 || a == rmax) st[a] = 0;
@@ -1409,6 +1551,13 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   const bool overflow = __any(mych > 8) || d.n > 65535;
   for (int off = 32; off > 0; off >>= 1) { chg += __shfl_xor(chg, off); rmax = min(rmax, __shfl_xor(rmax, off)); }
   const int tot = chg;
+  // fp64-grade multipliers: an fp64 solve, or a corrected f32 solve whose residual -- S lam is in this round's GEMM row -- is at the
+  // fp64 floor (the fp64 kernel leaves ~5e-15 |b| at these sizes)
+  bool grade64 = !f32_phase && d.prec[p] != 0;
+  if (rdo == 2) {
+    for (int off = 32; off > 0; off >>= 1) { res_r = fmax(res_r, __shfl_xor(res_r, off)); res_b = fmax(res_b, __shfl_xor(res_b, off)); }
+    grade64 = !f32_phase && res_r <= ASM_REFINE_TOL * res_b;
+  }
   if (tot > 0) {
     int single = 0;
     if (lane == 0) {
@@ -1428,7 +1577,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
       }
     }
   }
-  const bool settled = tot == 0 && !f32_phase;               // a set that settles in f32 is solved again in fp64
+  const bool settled = tot == 0 && grade64;                  // a set that settles in f32 is solved again in fp64
   const bool settle_wide = settled && W < d.n;               // settled inside the window: full-width check next
   // the LAM row goes back to zero (rows are handed out anew every round) -- except the row of a problem that settled inside the
   // window: the full-width pass at the start of the next round runs on it as it stands (asm_wide_k clears it afterwards)
@@ -1463,11 +1612,12 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
     const int rd = d.rounds[p] + 1;
     d.rounds[p] = rd;
     if (tot > 0 && d.hi[p] < W) d.hi[p] = W;                 // bounds inside the window may have joined
-    if (tot == 0 && f32_phase) d.prec[p] = 1;
+    const bool refine_next = d.refine_later && m <= ASM_MLDS;   // (the classes asm_lambda_reg serves: larger sets keep the f32 -> fp64 ladder)
+    if (tot == 0 && !grade64 && !(f32_phase && refine_next)) d.prec[p] = 1;   // (refine_later: the next round solves it in f32 with the fp64 correction)
     // ... and so is one that is about to: when at most early64 bounds moved, the next set is most often the final one, and
     // solving it in fp64 at once saves the f32 round that would only have confirmed it (CDU batch: 4.65 -> 3.7 f32 solves
     // per problem, still one fp64 solve for nine in ten)
-    if (tot > 0 && tot <= d.early64 && f32_phase) d.prec[p] = 1;
+    if (tot > 0 && tot <= d.early64 && f32_phase && !refine_next) d.prec[p] = 1;
     if (settle_wide) d.state[p] = ASM_WIDE;
     else if (settled) {
       d.state[p] = sure ? ASM_CERT : ASM_DONE;

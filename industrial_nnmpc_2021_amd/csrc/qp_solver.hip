@@ -33,6 +33,7 @@
 #include "qp_small.h"
 #include "qp_predict.h"
 #include "common.h"
+static constexpr int ASM_SMALL9_LDS_MAX = 100 * 1024;   // dynamic LDS the nine-block instance of asm_small_k may ask for (81 KB at n = 1024, nu = 64)
 
 using namespace nnmpc;
 
@@ -1072,6 +1073,7 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.nseg = nprob;
   { static const int tgi = getenv("NNMPC_TAIL_GI") ? 1 : 0; a.tail_gi = tgi; }   // (the variable: diagnostics, A/B of the tail's exchange rule)
   { static const int wg = getenv("NNMPC_NO_WG") ? 0 : 1; a.use_wg = wg; }   // (the variable: diagnostics, A/B against the kernels it replaced)
+  { static const int rfn = getenv("NNMPC_REFINE") ? atoi(getenv("NNMPC_REFINE")) : 1; a.refine = 0; a.refine_later = rfn && a.use_f32; }   // (the variable: diagnostics, A/B against separate f32 and fp64 rounds)
   { static const int e64 = getenv("NNMPC_EARLY64") ? atoi(getenv("NNMPC_EARLY64")) : 4; a.early64 = e64; }   // (the variable: diagnostics, A/B of the rule)
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
   // asm_update_k / asm_wide_k of the same round
@@ -1154,7 +1156,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
     // ... and the sets that outgrow its 112 bounds (one problem in two of three 10 000-problem batches of the CSTRs-size plant: handed
     // to the lock-step machinery it cost a round of bookkeeping launches, a read-back and 30 more iterations in the device tail -- 2.7 -
     // 3.1 ms per step against 1.4 without such a problem) carry on in a nine-block instance; a wave whose problem is finished exits at once
-    hipLaunchKernelGGL((asm_small_k<9, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(9, h->n, h->nu), s, a, a.max_rounds, g0);
+    if (asm_small_lds_bytes(9, h->n, h->nu) <= ASM_SMALL9_LDS_MAX)   // (else: handed on as before)
+      hipLaunchKernelGGL((asm_small_k<9, 1, 8>), dim3(nprob), dim3(64), asm_small_lds_bytes(9, h->n, h->nu), s, a, a.max_rounds, g0);
     h->stats.asm_rounds += 1;
     h->stats.asm_small_passes += 1;
     static const bool trace = getenv("NNMPC_TRACE_ROUNDS") != nullptr;   // diagnostics: iterations and set sizes per problem
@@ -1251,6 +1254,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
       hipLaunchKernelGGL(asm_wide_k, dim3((prev_rows + 3) / 4), dim3(256), 0, s, a, fused_c0);
     }
     a.kref = kprev;
+    if (!a.pred_w) a.refine_later = 0;                   // (only behind predicted first sets: from other starts the f32 rounds are many and their sets still move)
+    a.refine = a.refine_later && rounds >= 1;            // round 0 stays the plain f32 screen
     {
       EvScope es(h, 6, 0.0);                            // set bookkeeping: counted with asm_update_k
       hipLaunchKernelGGL(asm_count_k, dim3((nprob + 3) / 4), dim3(256), 0, s, a);
@@ -1565,7 +1570,7 @@ int nnmpc_qp_create(nnmpc_qp** out, int32_t n, int32_t nu, int32_t n_aug, const 
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k<WIDE_LAZY>, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_gemm_k<WIDE_FAR>, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_wide_t_k, hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_small_k<9, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, asm_small_lds_bytes(9, ASM_SM_NMAX, 64));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)asm_small_k<9, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ASM_SMALL9_LDS_MAX);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_f32_kdyn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<128>::LDS_FLOATS * 4);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); nnmpc_qp_destroy(h); return NNMPC_EHIP; }
   }
