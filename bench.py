@@ -493,12 +493,13 @@ def multiplier_family(st, traffic):
     tr, tr_step, tr_l = _traffic_of(traffic, ["asm_lambda_reg32_k", "asm_lambda_reg_k", "asm_lambda_reg32b_k", "asm_lambda_wg64s_k", "asm_lambda_wg32_k",
                                               "asm_lambda_wg64_k", "asm_lambda_tile_k<1>", "asm_lambda_reg2_k"])
     launches = int(st["asm_lambda32_launches"] + st["asm_lambda64_launches"])
-    return {"kernel": "multiplier family: asm_lambda_reg32_k (f32 rounds) + asm_lambda_reg_k (fp64) + side-stream classes > 144 bounds",
+    return {"kernel": "multiplier family: asm_lambda_reg32_k (f32 rounds; from round 1 with one fp64 correction) + asm_lambda_reg_k (fp64) + side-stream classes > 144 bounds",
             "dtype": "f32+f64", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": tr,
             "traffic_per_step": tr_step, "launches": launches, "avg_launch_ms": ms / max(1, launches), "time_share": ms / st["total_ms"],
             "kernel_ms": ms, "f32_flops": f32, "f64_flops": f64, "f32_instance_ms": st["asm_lambda32_ms"], "f64_instance_ms": st["asm_lambda64_ms"],
             "side_stream_ms": st["asm_side_ms"],
             "algorithmic_flops": "m^3/3 + 2 m^2 per problem and round (m = size of its active set), f32 rounds priced at 157.3, fp64 at 78.6 TFLOP/s; "
+                                 "the fp64 correction of an f32 solve (2 m^2 gathered fp64 FMAs + two substitutions) is in the time, not in the flops; "
                                  "time = hipEvents around the whole family of a round (main stream, side streams joined)"}
 
 
