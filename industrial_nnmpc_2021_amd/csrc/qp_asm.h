@@ -158,6 +158,7 @@ struct AsmDev {
   int tail_gi;                     // asm_tail_k: dual active-set steps (Goldfarb-Idnani) instead of Murty's single exchanges once block exchanges stop making progress (off: measured slower, see there)
   int use_wg;                      // sets of 145 .. 256 bounds go to the four-wave register kernels (qp_wg.h); 0: the single-wave / LDS-tile / slab kernels (A/B)
   int refine;                      // f32 rounds of sets of <= ASM_MLDS bounds get rows of LAM (fp64) and correct a result that can be final in fp64 (asm_reg_core)
+  double refine_tol;               // residual of a corrected f32 solve, relative to max |b|, that counts as an fp64 solve (ASM_REFINE_TOL)
   int refine_later;                // ... from the next round on (this one may still be a plain f32 screen): a set that settles in f32 now is NOT sent to the fp64 kernel
   int early64;                     // an f32 round that moves at most this many bounds is followed by an fp64 round (0: only a settled set is)
   int* wflag;                      // [nseg] set by asm_wide_gemm_k when a bound beyond the window is violated (cleared by asm_wide_k)
@@ -1556,7 +1557,7 @@ __global__ __launch_bounds__(256) void asm_update_k(AsmDev d) {   // one WAVE pe
   bool grade64 = !f32_phase && d.prec[p] != 0;
   if (rdo == 2) {
     for (int off = 32; off > 0; off >>= 1) { res_r = fmax(res_r, __shfl_xor(res_r, off)); res_b = fmax(res_b, __shfl_xor(res_b, off)); }
-    grade64 = !f32_phase && res_r <= ASM_REFINE_TOL * res_b;
+    grade64 = !f32_phase && res_r <= d.refine_tol * res_b;
   }
   if (tot > 0) {
     int single = 0;

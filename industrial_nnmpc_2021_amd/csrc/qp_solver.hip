@@ -1073,7 +1073,8 @@ int solve_segment_asm(nnmpc_qp* h, int nprob, const double* x0_dev, const double
   a.nseg = nprob;
   { static const int tgi = getenv("NNMPC_TAIL_GI") ? 1 : 0; a.tail_gi = tgi; }   // (the variable: diagnostics, A/B of the tail's exchange rule)
   { static const int wg = getenv("NNMPC_NO_WG") ? 0 : 1; a.use_wg = wg; }   // (the variable: diagnostics, A/B against the kernels it replaced)
-  { static const int rfn = getenv("NNMPC_REFINE") ? atoi(getenv("NNMPC_REFINE")) : 1; a.refine = 0; a.refine_later = rfn && a.use_f32; }   // (the variable: diagnostics, A/B against separate f32 and fp64 rounds)
+  { static const int rfn = getenv("NNMPC_REFINE") ? atoi(getenv("NNMPC_REFINE")) : 1; a.refine = 0; a.refine_later = rfn && a.use_f32;
+    static const double rtol = getenv("NNMPC_REFINE_TOL") ? atof(getenv("NNMPC_REFINE_TOL")) : ASM_REFINE_TOL; a.refine_tol = rtol; }   // (the variable: diagnostics, A/B against separate f32 and fp64 rounds)
   { static const int e64 = getenv("NNMPC_EARLY64") ? atoi(getenv("NNMPC_EARLY64")) : 4; a.early64 = e64; }   // (the variable: diagnostics, A/B of the rule)
   // LAM / LAMW are all zero between calls: every entry the multiplier kernels write is cleared again by
   // asm_update_k / asm_wide_k of the same round
