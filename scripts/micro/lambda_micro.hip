@@ -107,7 +107,7 @@ int main(int argc, char** argv) {
     d.H32 = dH32;
   }
   float* dlam32; CK(hipMalloc(&dlam32, xunc.size() * 4)); CK(hipMemset(dlam32, 0, xunc.size() * 4)); d.lam32 = dlam32;
-  unsigned char* drowk; CK(hipMalloc(&drowk, nseg)); CK(hipMemset(drowk, 1, nseg)); d.rowk = drowk;
+  unsigned char* drowk; CK(hipMalloc(&drowk, nseg)); CK(hipMemset(drowk, variant == 20 ? 0 : 1, nseg)); d.rowk = drowk;   // variant 20: the f32 register kernels with rows of LAM -- every solve gets its fp64 correction (build with -DASM_REFINE_ALWAYS: the synthetic sets have random multiplier signs)
   int* drow; CK(hipMalloc(&drow, nseg * 4)); CK(hipMemcpy(drow, list.data(), nseg * 4, hipMemcpyHostToDevice)); d.row = drow;
   const int mbc = asm_bin_cap(bin) / 16;
   const int lds_tile = (asm_bin_cap(bin) + ASM_TS + mbc * (mbc + 1) / 2 * ASM_TS) * 8;
@@ -146,8 +146,8 @@ int main(int argc, char** argv) {
     } else
 #endif
     if (variant == 0) hipLaunchKernelGGL((asm_lambda_tile_k<0>), dim3(nseg), dim3(256), lds_tile, 0, d, bin);
-    else if (variant == 2 && bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG32_LDS, 0, d);
-    else if (variant == 2) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3((nseg + 3) / 4 + 2), dim3(256), ASM_REG32B_LDS, 0, d);
+    else if ((variant == 2 || variant == 20) && bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg32_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG32_LDS, 0, d);
+    else if (variant == 2 || variant == 20) hipLaunchKernelGGL(asm_lambda_reg32b_k, dim3((nseg + 3) / 4 + 2), dim3(256), ASM_REG32B_LDS, 0, d);
     else {
       if (bin < ASM_NREG) hipLaunchKernelGGL(asm_lambda_reg_k, dim3((nseg + 3) / 4 + ASM_NREG), dim3(256), ASM_REG_LDS, 0, d);
       else hipLaunchKernelGGL(asm_lambda_reg2_k, dim3((nseg + 1) / 2 + 2), dim3(128), ASM_REG2_LDS, 0, d);
@@ -161,6 +161,11 @@ int main(int argc, char** argv) {
   std::vector<int> state(nseg);
   CK(hipMemcpy(state.data(), dstate, nseg * 4, hipMemcpyDeviceToHost));
   int nfb = 0; for (int s : state) nfb += s != 0;
+  if (variant == 20) {
+    std::vector<unsigned char> rd(nseg); CK(hipMemcpy(rd.data(), dredo, nseg, hipMemcpyDeviceToHost));
+    int n2 = 0; for (auto v : rd) n2 += v == 2;
+    printf("corrected in fp64: %d of %d\n", n2, nseg);
+  }
   double worst = 0.0;
   for (int pp = 0; pp < 2; ++pp) {
     const int p = pp == 0 ? 0 : nseg - 1;
